@@ -1,0 +1,14 @@
+"""cudaraytracing_amd -- MI355X-native Monte-Carlo path tracer with the
+config.json / Scene / Render surface of guomc9/CudaRayTracing.
+
+The package is a thin ctypes layer over lib/libcrt.so (C ABI: include/crt.h),
+which holds the C++ host side (OBJ/MTL loader, median-split BVH, flat scene
+export) and the hand-written HIP kernels for gfx950.
+"""
+from .api import (Render, Scene, Task, device_count, device_math, device_philox, fov_to_radians,
+                  get_inverse_view_matrix, shard_slots)
+from ._capi import (FLAG_STATS, FLAG_TILED_OUTPUT, TRAVERSAL_FAST, TRAVERSAL_REFERENCE, CrtError)
+
+__all__ = ["Render", "Scene", "Task", "device_count", "device_math", "device_philox", "fov_to_radians",
+           "get_inverse_view_matrix", "shard_slots", "FLAG_STATS", "FLAG_TILED_OUTPUT", "TRAVERSAL_FAST",
+           "TRAVERSAL_REFERENCE", "CrtError"]

@@ -1,0 +1,65 @@
+"""Builds the native parts of cudaraytracing_amd in-tree.
+
+  lib/libcrt.so   HIP kernels (gfx950) + host layer + C ABI   (hipcc)
+  lib/crt_cli     headless config.json -> PNG command line     (hipcc, links libcrt.so)
+
+The flags matter for bit parity with the CPU oracle: no FMA contraction, no
+fast-math, correctly rounded fp32 divide / sqrt on the device.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcrt.so")
+CLI = os.path.join(LIBDIR, "crt_cli")
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+
+LIB_SOURCES = ["crt_kernels.hip", "crt_host.cpp"]
+LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_detmath.h", "crt_host.hpp", os.path.join("..", "..", "include", "crt.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and not _stale(LIB, LIB_DEPS):
+        return LIB
+    cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_cli(force=False, verbose=False):
+    src = os.path.join(CSRC, "crt_cli.cpp")
+    if not os.path.exists(src):
+        return None
+    if not force and not _stale(CLI, ["crt_cli.cpp", "crt_host.hpp"]) and os.path.getmtime(CLI) >= os.path.getmtime(LIB):
+        return CLI
+    cmd = [HIPCC] + COMMON + [src, "-L" + LIBDIR, "-lcrt", "-Wl,-rpath,$ORIGIN", "-o", CLI]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_cli(force, verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,86 @@
+// cudaraytracing_amd/csrc/crt_device.h -- device-side data model and small
+// vector helpers shared by the HIP kernels and the upload code.
+//
+// HBM layout (all read-only during a render, replicated per GPU):
+//   nodes      4 x float4 per INNER node, breadth-first order (root = 0):
+//                [0] = (left.lo.xyz , bits(left_ref))   [1] = (left.hi.xyz , bits(right_ref))
+//                [2] = (right.lo.xyz, 0)                [3] = (right.hi.xyz, 0)
+//              both child boxes live in the parent: one 64 B fetch per inner-node
+//              visit instead of the reference's 3 x 40 B (DeviceBVH.cuh:140,151-152).
+//              child ref >= 0: inner node index; < 0: leaf, ~ref = (first_tri << 4) | n
+//              with n in 1..15 (n = 0: count looked up in leaf_count[first_tri]).
+//   tri_geo    3 x float4 per triangle (BVH order): (v1.xyz, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz)
+//              48 B instead of the reference's 140 B DeviceTriangle.
+//   tri_mat    int32 material index per triangle
+//   mats       3 x float4 per material: (kd/pi .xyz, ns) (kd.xyz, bits(flags)) (ke.xyz, 0)
+//              flags bit0 = has_emit, bit1 = SPECULAR
+//   ltri       4 x float4 per light triangle (shape order): (v1.xyz, v2.x) (v2.yz, v3.xy)
+//              (v3.z, n.xyz) (ke.xyz, area_of_obj)
+//   lights     uint2 (first, count) per light object
+#ifndef CRT_DEVICE_H
+#define CRT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "crt_detmath.h"
+
+namespace crtdev {
+
+#define CRT_EPSILON 0.00001f       /* reference: include/Global.h:11 */
+#define CRT_BOUNCE_STACK_SIZE 64   /* reference: include/Global.h:18 */
+#define CRT_TILE 8                 /* pixel tile edge used for sharding */
+
+struct DevScene {
+    const float4* nodes;
+    const float4* tri_geo;
+    const int32_t* tri_mat;
+    const float4* mats;
+    const float4* ltri;
+    const uint2* lights;
+    const int32_t* leaf_count; // only read for leaves with more than 15 triangles
+    int32_t root_ref;
+    int32_t n_lights;
+};
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ F3 add3(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 sub3(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 mul3(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 scale3(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }   // v * s
+__device__ __forceinline__ F3 scalel3(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }  // s * v
+__device__ __forceinline__ F3 div3(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// Eigen reduction order: p0 + (p1 + p2)
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b)
+{
+    return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float norm3(F3 a) { return sqrt_f(dot3(a, a)); }
+__device__ __forceinline__ F3 unit3(F3 a)
+{
+    float z = dot3(a, a);
+    if (z > 0.0f) { float s = sqrt_f(z); return f3(a.x / s, a.y / s, a.z / s); }
+    return a;
+}
+__device__ __forceinline__ float maxf_ref(float x, float y) { return x > y ? x : y; } // Global.h:111-114
+__device__ __forceinline__ float minf_ref(float x, float y) { return x < y ? x : y; } // Global.h:116-119
+
+struct RayT {
+    F3 o, d, inv;
+};
+// reference: include/Ray.cuh:12-15 (direction is normalised again, inv_dir may be +-inf)
+__device__ __forceinline__ RayT make_ray(F3 o, F3 d)
+{
+    RayT r;
+    r.o = o;
+    r.d = unit3(d);
+    r.inv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z);
+    return r;
+}
+
+} // namespace crtdev
+#endif

@@ -1,0 +1,65 @@
+"""Multi-GPU sharding of the frame: pixel tiles interleaved over ranks, one
+RCCL all-gather of the compact per-rank tile buffers, then a de-interleave.
+
+The reference has no multi-GPU path (config_CUDA hard-selects device 0,
+src/main.cu:99-100); pixels are independent and the RNG is keyed by the global
+pixel index, so the image does not depend on the partition.
+
+Tile t (8x8 pixels, row-major over ceil(W/8) x ceil(H/8)) belongs to rank
+t % world; rank r stores its k-th tile (t = k*world + r) at slots [64k, 64k+64).
+"""
+import numpy as np
+
+TILE = 8
+
+
+def tile_grid(width, height):
+    return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+
+
+def local_tiles(width, height, world):
+    tx, ty = tile_grid(width, height)
+    return (tx * ty + world - 1) // world
+
+
+def untile_numpy(gathered, width, height):
+    """gathered: (world, slots, C) array of per-rank compact tile buffers -> (H, W, C) image."""
+    world, slots, ch = gathered.shape
+    tx, ty = tile_grid(width, height)
+    lt = slots // 64
+    a = gathered.reshape(world, lt, TILE, TILE, ch)
+    a = np.transpose(a, (1, 0, 2, 3, 4)).reshape(lt * world, TILE, TILE, ch)[:tx * ty]
+    a = a.reshape(ty, tx, TILE, TILE, ch)
+    a = np.transpose(a, (0, 2, 1, 3, 4)).reshape(ty * TILE, tx * TILE, ch)
+    return np.ascontiguousarray(a[:height, :width])
+
+
+def untile_torch(gathered, width, height):
+    """Same as untile_numpy for a torch tensor (stays on its device)."""
+    world, slots, ch = gathered.shape
+    tx, ty = tile_grid(width, height)
+    lt = slots // 64
+    a = gathered.reshape(world, lt, TILE, TILE, ch).permute(1, 0, 2, 3, 4).reshape(lt * world, TILE, TILE, ch)[:tx * ty]
+    a = a.reshape(ty, tx, TILE, TILE, ch).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, ch)
+    return a[:height, :width].contiguous()
+
+
+def render_sharded(render, eye, inv_view, fov_y, width, height, rank, world, device, group=None, want_stats=True):
+    """One process per GPU: renders this rank's tiles into a torch uint8 tensor, all-gathers
+    the compact buffers over RCCL (torch.distributed backend "nccl") and returns
+    (image tensor (H, W, 3) on `device`, stats of this rank).  world == 1 skips the collective."""
+    import torch
+    import torch.distributed as dist
+    from .api import shard_slots
+
+    slots = shard_slots(width, height, rank, world)
+    local = torch.empty((slots, 3), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+    stats = render.run_view_device(eye, inv_view, fov_y, local.data_ptr(), None, stream, rank=rank, world=world,
+                                   tiled=True, want_stats=want_stats, width=width, height=height)
+    if world > 1:
+        gathered = torch.empty((world, slots, 3), dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=group)
+    else:
+        gathered = local.unsqueeze(0)
+    return untile_torch(gathered, width, height), stats

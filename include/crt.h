@@ -1,0 +1,225 @@
+/*
+ * include/crt.h -- C ABI of libcrt.so, the MI355X-native drop-in for the
+ * reference's rendering hot path.
+ *
+ * The reference (guomc9/CudaRayTracing) has no FFI layer: the boundary of the
+ * hot path is the C++ class `Render` (reference: include/Render.cuh:357-557)
+ * constructed from a `Scene*` and driven by `run_view` (src/main.cu:282,372).
+ * Every entry point below names the reference interface it replaces.  All
+ * signatures are plain C (pointers, sizes, PODs); no torch / HIP types.
+ * All functions return CRT_OK (0) or a negative crt_status; nothing prints and
+ * continues (the reference printf's CUDA errors and carries on,
+ * Render.cuh:393-397,441-473).
+ *
+ * Threading: one host thread per scene handle; handles are not shared across
+ * threads (the reference is single-threaded and not re-entrant either).
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+typedef enum {
+    CRT_OK = 0,
+    CRT_ERR_INVALID_ARG = -1,
+    CRT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init (reference: src/main.cu:92-105) */
+    CRT_ERR_HIP = -3,         /* a HIP call failed; see crt_last_error() */
+    CRT_ERR_UNSUPPORTED = -4, /* valid for the reference but outside this build (e.g. map_Kd textures) */
+    CRT_ERR_IO = -5,          /* file missing / unreadable */
+    CRT_ERR_PARSE = -6,       /* malformed OBJ / MTL / JSON */
+    CRT_ERR_OOM = -7
+} crt_status;
+
+const char* crt_strerror(int status);
+/* thread-local detail string of the last failure in this thread ("" if none) */
+const char* crt_last_error(void);
+int crt_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Flat scene description handed to the device layer.
+ * ---------------------------------------------------------------------- */
+
+/* BVH node exactly as the reference uploads it (DeviceBVHNode,
+ * include/DeviceBVH.cuh:9-15): post-order array, root = last; a node is a leaf
+ * iff lc < 0 && rc < 0; leaf triangles are [it, it+n) of the BVH-ordered
+ * triangle array. 40 bytes. */
+typedef struct {
+    int32_t lc, rc;
+    uint32_t n;
+    int32_t it;
+    float aa[3];
+    float bb[3];
+} crt_bvh_node;
+
+/* Triangle (reference DeviceTriangle, include/DeviceTriangle.cuh:12-37) with the
+ * per-triangle material copy replaced by an index into crt_material[]. */
+typedef struct {
+    float v1[3], v2[3], v3[3];
+    float normal[3];     /* geometric normal from winding (Triangle.h:27) */
+    float area;          /* Triangle.h:39 */
+    float area_of_obj;   /* Object.h:15-23 */
+    int32_t material;
+} crt_triangle;
+
+/* reference DeviceMaterial (include/DeviceMaterial.cuh:5-37); ks/ka are never
+ * read on the hot path and always zero (Loader.h:45,47,107). */
+typedef struct {
+    float kd[3];
+    float ke[3];
+    float ns;
+    int32_t mode;      /* 0 = DIFFUSE, 1 = SPECULAR (Material.h:7-10) */
+    int32_t has_emit;  /* Material.h:36-39 */
+} crt_material;
+
+/* One light object = a contiguous run of light_tris (reference DeviceLight,
+ * include/DeviceLights.cuh:5-31: its own unsorted triangle copies). */
+typedef struct {
+    uint32_t first_tri;
+    uint32_t count;
+} crt_light;
+
+typedef struct {
+    const crt_bvh_node* nodes;     uint32_t n_nodes;  int32_t root;
+    const crt_triangle* tris;      uint32_t n_tris;        /* BVH order */
+    const crt_material* materials; uint32_t n_materials;
+    const crt_triangle* light_tris; uint32_t n_light_tris;  /* shape order */
+    const crt_light* lights;       uint32_t n_lights;
+} crt_scene_desc;
+
+typedef struct {
+    float eye[3];
+    float inv_view[9]; /* column-major 3x3 (Eigen::Matrix3f storage), from crt_inverse_view */
+    float fov_y;       /* radians (src/main.cu:278) */
+} crt_camera;
+
+enum {
+    CRT_TRAVERSAL_FAST = 0,      /* ordered, pruned, any-hit shadow rays; results identical to REFERENCE */
+    CRT_TRAVERSAL_REFERENCE = 1  /* exhaustive traversal in the reference's visit order (DeviceBVH.cuh:128-170) */
+};
+enum {
+    CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (REFERENCE traversal only) */
+    CRT_FLAG_TILED_OUTPUT = 2u   /* write this rank's pixels in compact 8x8-tile order instead of row-major */
+};
+
+typedef struct {
+    uint32_t width, height;      /* Scene::width/height (Scene.h:28-31) */
+    uint32_t spp;                /* Render::spp (Render.cuh:362) */
+    float p_rr;                  /* Render::P_RR */
+    int32_t light_sample_n;      /* Render::light_sample_n */
+    uint64_t seed;               /* replaces clock() (Render.cuh:341) */
+    uint32_t rank, world;        /* pixel-tile shard: 8x8 tile t belongs to rank t % world; world >= 1 */
+    uint32_t traversal;          /* CRT_TRAVERSAL_* */
+    uint32_t flags;              /* CRT_FLAG_* */
+} crt_params;
+
+typedef struct {
+    uint64_t paths;              /* W*H*spp of this shard */
+    uint64_t rays;               /* closest-hit queries (= DeviceBVH::intersect calls) */
+    uint64_t shadow_rays, probe_rays;
+    uint64_t inner_pops, leaf_pops, tri_tests, hits; /* reference visit set; CRT_FLAG_STATS + REFERENCE only */
+    float kernel_ms;             /* HIP-event time of the path kernel(s), on their stream */
+    float total_ms;              /* HIP-event time of the whole device pipeline of this call */
+    uint32_t kernel_launches;
+    uint32_t reserved;
+} crt_stats;
+
+/* ------------------------------------------------------------------------
+ * Device layer
+ * ---------------------------------------------------------------------- */
+typedef struct crt_scene crt_scene;
+
+/* number of HIP devices visible (reference: config_CUDA, src/main.cu:92-105) */
+int crt_device_count(int* count);
+
+/* Upload a flat scene to `device` (replaces the DeviceBVH / DeviceLights /
+ * DeviceTriangle / DeviceMaterial constructors, DeviceBVH.cuh:52-80,
+ * DeviceLights.cuh:12-31,63-87, and the device half of Render's constructor,
+ * Render.cuh:387-414).  The per-pixel stack allocations of Render.cuh:416-422
+ * have no equivalent: traversal stacks live in LDS. */
+int crt_scene_create(const crt_scene_desc* desc, int device, crt_scene** out);
+/* replaces Render::free (Render.cuh:477-487) */
+int crt_scene_destroy(crt_scene* scene);
+
+/* Number of pixel slots a shard writes with CRT_FLAG_TILED_OUTPUT:
+ * ceil(n_tiles_of_rank) * 64, n_tiles = ceil(W/8)*ceil(H/8). */
+int crt_shard_slots(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint64_t* slots);
+
+/* Render one frame and copy it to host memory: replaces Render::run_view
+ * (Render.cuh:435-475: kernel launch, synchronize, D2H copy; the OpenGL PBO
+ * copy is dropped).  out_rgb: 3 bytes per pixel, row-major, row 0 = image top
+ * (W*H*3 bytes, or slots*3 with CRT_FLAG_TILED_OUTPUT).  out_mean (optional,
+ * may be NULL): pre-tone-map mean radiance, 3 floats per pixel, same order.
+ * stats optional. */
+int crt_render(crt_scene* scene, const crt_camera* cam, const crt_params* params, uint8_t* out_rgb,
+               float* out_mean, crt_stats* stats);
+
+/* Same, but outputs stay in device memory (d_rgb / d_mean are device pointers
+ * on the scene's device, d_mean may be NULL) and the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = default stream) without synchronizing.
+ * If stats != NULL the call synchronizes the stream to read counters/timers. */
+int crt_render_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, void* d_rgb,
+                      void* d_mean, void* hip_stream, crt_stats* stats);
+
+/* Closest-hit query for n rays (device-side DeviceBVH::intersect,
+ * DeviceBVH.cuh:128-170), host buffers. dirs are normalised as Ray's
+ * constructor does (Ray.cuh:12-15). out_tri: BVH-order triangle index or -1. */
+int crt_intersect(crt_scene* scene, uint32_t n, const float* origins, const float* dirs, uint32_t traversal,
+                  int32_t* out_tri, float* out_t);
+
+/* Device-side evaluation of the deterministic math / RNG helpers, for parity
+ * tests against the oracle.  fn in {"sin","cos","tan","acos","atan2","exp","log10","pow","uniform"}. */
+int crt_device_math(int device, const char* fn, uint32_t n, const float* a, const float* b, float* out);
+int crt_device_philox(int device, uint32_t n, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
+
+/* ------------------------------------------------------------------------
+ * Host layer: scene ingestion and BVH build on the CPU (north star: "C++ host
+ * code builds the BVH and triangle/material/light arrays as today").
+ * Mirrors Scene / Loader / Object / BVH / Camera of the reference.
+ * ---------------------------------------------------------------------- */
+typedef struct crt_host_scene crt_host_scene;
+
+/* Scene(width, height)  (Scene.h:28-31) */
+int crt_host_scene_create(uint32_t width, uint32_t height, crt_host_scene** out);
+int crt_host_scene_destroy(crt_host_scene* scene); /* Scene::free */
+/* Loader::read_OBJ + load_object for every shape + Scene::add_normal_obj/add_light_obj
+ * in shape order (src/main.cu:122-145) */
+int crt_host_scene_add_obj(crt_host_scene* scene, const char* obj_path, const char* mtl_dir);
+/* Scene::set_BVH(thresh_n) (Scene.h:50-54 -> BVH.h:30-84) */
+int crt_host_scene_set_bvh(crt_host_scene* scene, uint32_t thresh_n);
+/* Flat view of the built scene; pointers stay valid until the host scene is
+ * destroyed or modified. */
+int crt_host_scene_desc(const crt_host_scene* scene, crt_scene_desc* out);
+int crt_host_scene_num_objects(const crt_host_scene* scene, uint32_t* n);
+/* Object area as printed by the reference (Object.h:25) and whether it is a light */
+int crt_host_scene_object(const crt_host_scene* scene, uint32_t index, float* area, int32_t* is_light,
+                          uint32_t* n_tris);
+
+/* get_inverse_view_matrix (Camera.h:9-36); out = 9 floats column-major */
+int crt_inverse_view(const float eye[3], const float lookat[3], const float up[3], float out[9]);
+
+/* Task / config.json (src/main.cu:40-90) */
+typedef struct {
+    uint32_t n_objs;
+    char obj_path[8][512];
+    char mtl_dir[8][512];
+    float lookat[3], up[3], eye_pos[3];
+    float fov_y;        /* degrees, as in the file */
+    uint32_t width, height, bvh_thresh_n, light_sample_n, spp;
+    float p_rr;
+} crt_task;
+int crt_task_load(const char* config_json_path, crt_task* out);
+
+/* stb-free PNG writer used by Render::save_frame_buffer's replacement (Render.cuh:489-493) */
+int crt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

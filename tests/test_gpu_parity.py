@@ -1,0 +1,190 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact on the float mean-radiance buffer (the north star allows 1e-5; the
+design makes it exact, so the tests assert exact and report max |delta|), exact RGB8.
+"""
+import numpy as np
+import pytest
+
+import cudaraytracing_amd as crt
+import oracle_lib as O
+import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north-star tolerance on the float radiance buffer
+
+
+@pytest.fixture(scope="module")
+def renders():
+    out = {}
+    for name in ("cornell-box", "veach-mis"):
+        t = util.task(name)
+        out[name] = crt.Render(util.host_scene(name), t.spp, t.P_RR, t.light_sample_n)
+    yield out
+    for r in out.values():
+        r.free()
+
+
+def test_device_present():
+    assert crt.device_count() >= 1
+
+
+@pytest.mark.parametrize("fn,lo,hi", [("sin", -50, 50), ("cos", -50, 50), ("tan", -1.5, 1.5), ("acos", -1, 1),
+                                      ("exp", -30, 30), ("log10", 1e-6, 1e5), ("sincos_s", -50, 50),
+                                      ("sincos_c", -50, 50)])
+def test_device_math_matches_oracle(fn, lo, hi):
+    rng = np.random.default_rng(7)
+    x = rng.uniform(lo, hi, 200000).astype(np.float32)
+    x[:8] = [0.0, -0.0, lo, hi, 1.0, -1.0, 0.5, -0.5]
+    got = crt.device_math(fn, x)
+    ref = O.math_fn({"sincos_s": "sin", "sincos_c": "cos"}.get(fn, fn), x)
+    assert np.array_equal(util.bits(got), util.bits(ref))
+
+
+def test_device_math_two_arg_and_uniform():
+    rng = np.random.default_rng(8)
+    y = rng.normal(size=100000).astype(np.float32)
+    x = rng.normal(size=100000).astype(np.float32)
+    x[:4] = 0.0
+    assert np.array_equal(util.bits(crt.device_math("atan2", y, x)), util.bits(O.math_fn("atan2", y, x)))
+    c = rng.uniform(0, 1, 100000).astype(np.float32)
+    c[:3] = [0.0, 1.0, 0.5]
+    e = np.full_like(c, 0.6)
+    assert np.array_equal(util.bits(crt.device_math("pow", c, e)), util.bits(O.math_fn("pow", c, e)))
+    u = rng.integers(0, 2**32, 100000, dtype=np.uint64).astype(np.uint32)
+    u[:3] = [0, 0xFFFFFFFF, 0x80000000]
+    got = crt.device_math("uniform", u.view(np.float32))
+    ref = (u.astype(np.float32) * np.float32(2.3283064365386963e-10) + np.float32(1.1641532182693481e-10)).astype(np.float32)
+    assert np.array_equal(util.bits(got), util.bits(ref))
+    assert got.min() > 0.0 and got.max() <= 1.0
+
+
+def test_device_philox_matches_oracle_and_kat():
+    ctr = np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32)
+    key = np.array([[0, 0], [0xFFFFFFFF] * 2, [0xA4093822, 0x299F31D0]], dtype=np.uint32)
+    got = crt.device_philox(ctr, key)
+    kat = np.array([[0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8], [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD],
+                    [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]], dtype=np.uint32)
+    assert np.array_equal(got, kat)
+    rng = np.random.default_rng(3)
+    c = rng.integers(0, 2**32, (4096, 4), dtype=np.uint64).astype(np.uint32)
+    k = rng.integers(0, 2**32, (4096, 2), dtype=np.uint64).astype(np.uint32)
+    got = crt.device_philox(c, k)
+    ref = np.stack([O.philox(c[i], k[i]) for i in range(0, 4096, 37)])
+    assert np.array_equal(got[::37], ref)
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST])
+def test_intersect_matches_oracle(renders, name, mode):
+    o, d = util.random_rays(name, 4096, seed=11)
+    tri, t = renders[name].intersect(o, d, traversal=mode)
+    otri, ot, _ = util.oracle_scene(name).intersect(o, d)
+    assert np.array_equal(tri, otri)
+    assert np.array_equal(util.bits(t), util.bits(ot))
+    assert (tri >= 0).sum() > 1000
+
+
+CROPS = {"cornell-box": [(368, 268, 64, 48), (0, 0, 32, 24), (768, 576, 32, 24), (150, 330, 48, 32)],
+         "veach-mis": [(368, 268, 64, 48), (250, 150, 48, 32), (100, 400, 48, 32)]}
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST])
+def test_render_crops_match_oracle(renders, name, mode):
+    """800x600 at the scene's own config (C1 for cornell): crops against the oracle."""
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.traversal = mode
+    r.set_spp(4)
+    rgb = r.run_view(eye, iv, fov)
+    mean = r.mean_buffer
+    assert r.stats["paths"] == 800 * 600 * 4
+    osc = util.oracle_scene(name)
+    for (x0, y0, cw, ch) in CROPS[name]:
+        orgb, omean, _, st = osc.render(eye, iv, fov, t.width, t.height, 4, t.P_RR, t.light_sample_n, seed=0,
+                                        crop=(x0, y0, cw, ch))
+        g = mean[y0:y0 + ch, x0:x0 + cw]
+        delta = np.abs(g.astype(np.float64) - omean.astype(np.float64))
+        n_bad = int((~(delta <= TOL)).any(axis=2).sum())
+        assert n_bad == 0, "%s crop %s: %d pixels beyond %g (max %g)" % (name, (x0, y0, cw, ch), n_bad, TOL, np.nanmax(delta))
+        assert np.array_equal(util.bits(g), util.bits(omean)), "float buffer not bit-identical"
+        assert np.array_equal(rgb[y0:y0 + ch, x0:x0 + cw], orgb)
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_small_full_frame_matches_oracle_with_counters(renders, name):
+    """Whole 96x72 frame incl. ragged 8x8 tiles, ray counters against the oracle's."""
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.traversal = crt.TRAVERSAL_REFERENCE
+    r.set_spp(3)
+    w, h = 100, 75  # not multiples of 8
+    rgb = r.run_view(eye, iv, fov, stats=True, width=w, height=h)
+    orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, w, h, 3, t.P_RR, t.light_sample_n)
+    assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
+    assert np.array_equal(rgb, orgb)
+    for k in ("paths", "rays", "shadow_rays", "probe_rays", "inner_pops", "leaf_pops", "tri_tests", "hits"):
+        assert r.stats[k] == st[k], k
+    r.traversal = crt.TRAVERSAL_FAST
+    rgb2 = r.run_view(eye, iv, fov, width=w, height=h)
+    assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
+    assert np.array_equal(rgb2, orgb)
+    assert r.stats["rays"] == st["rays"]
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_fast_equals_reference_full_frame(renders, name):
+    """Full 800x600 frame: pruned/any-hit traversal is bit-identical to the exhaustive one."""
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.set_spp(8)
+    r.traversal = crt.TRAVERSAL_REFERENCE
+    r.run_view(eye, iv, fov)
+    ref = r.mean_buffer.copy()
+    r.traversal = crt.TRAVERSAL_FAST
+    r.run_view(eye, iv, fov)
+    assert np.array_equal(util.bits(ref), util.bits(r.mean_buffer))
+
+
+def test_seed_changes_image_and_is_reproducible(renders):
+    eye, iv, fov = util.camera("cornell-box")
+    r = renders["cornell-box"]
+    r.traversal = crt.TRAVERSAL_FAST
+    r.set_spp(2)
+    a = r.run_view(eye, iv, fov, width=160, height=120).copy()
+    b = r.run_view(eye, iv, fov, width=160, height=120).copy()
+    r.seed = 1234567890123
+    c = r.run_view(eye, iv, fov, width=160, height=120).copy()
+    orgb, omean, _, _ = util.oracle_scene("cornell-box").render(eye, iv, fov, 160, 120, 2, 0.6, 2, seed=1234567890123)
+    r.seed = 0
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, c)
+    assert np.array_equal(c, orgb)
+
+
+def test_sharded_render_reassembles(renders):
+    """world=3 tile shards written in compact tile order reassemble to the single-GPU image."""
+    import ctypes as C
+    from cudaraytracing_amd import _capi as capi
+    from cudaraytracing_amd.distributed import untile_numpy
+    eye, iv, fov = util.camera("veach-mis")
+    r = renders["veach-mis"]
+    r.traversal = crt.TRAVERSAL_FAST
+    r.set_spp(2)
+    w, h = 200, 150
+    full = r.run_view(eye, iv, fov, width=w, height=h).copy()
+    world = 3
+    shards = []
+    for rank in range(world):
+        slots = crt.shard_slots(w, h, rank, world)
+        buf = np.zeros((slots, 3), dtype=np.uint8)
+        prm = r._params(rank=rank, world=world, flags=capi.FLAG_TILED_OUTPUT, width=w, height=h)
+        cam = r._cam(eye, iv, fov)
+        capi.check(capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), None, None), "crt_render")
+        shards.append(buf)
+    img = untile_numpy(np.stack(shards), w, h)
+    assert np.array_equal(img, full)
