@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame on cornell-box 800x600 spp=512
+(BASELINE.json configs[1]) on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one complete frame: every rank path-traces its interleaved 8x8 pixel
+tiles with the HIP kernels of libcrt.so, the compact RGB8 tile buffers are
+all-gathered over RCCL and de-interleaved into the final image on every rank.
+The total work is fixed as N grows ("strong" scaling).
+
+A ray is one closest-hit query of the reference (DeviceBVH::intersect): primary,
+bounce, shadow and specular-probe rays; the count is deterministic given
+(scene, config, seed) and comes from the kernel's counters.
+
+roofline: algorithmic bytes = rays x B_ray, B_ray = 64 B x inner-node visits +
+8 B x leaf visits + 36 B x triangle tests + 16 B x hits of the REFERENCE
+traversal's visit set, measured with the exhaustive counting
+kernel on a spp=8 slice of the same frame; achieved = bytes / HIP-event time of
+the path kernel; peak = 8 TB/s HBM3E.  The scene (a few MB) is cache resident,
+so real HBM traffic is far below the algorithmic figure -- see DESIGN.md.
+
+cpu_baseline: the single-threaded CPU oracle (a port of the reference algorithm,
+oracle/crt_oracle.cpp) timed on this host on the same scene at 800x600 spp=2
+(BASELINE.json configs[0]), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell-box")
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--height", type=int, default=600)
+    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=2)
+    ap.add_argument("--save-png", default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import cudaraytracing_amd as crt
+    from cudaraytracing_amd.distributed import render_sharded
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    cfg = os.path.join(ROOT, "scenes", args.scene, "config.json")
+    task = crt.Task(cfg, base_dir=ROOT)
+    scene = crt.Scene.from_task(task, args.width, args.height)
+    eye = task.eye_pos
+    inv_view = crt.get_inverse_view_matrix(task.eye_pos, task.lookat, task.up)
+    fov = crt.fov_to_radians(task.fov_y)
+    render = crt.Render(scene, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
+    render.seed = args.seed
+    render.traversal = crt.TRAVERSAL_FAST if args.traversal == "fast" else crt.TRAVERSAL_REFERENCE
+
+    def step():
+        return render_sharded(render, eye, inv_view, fov, args.width, args.height, rank, world, device)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    rays_local = 0
+    img = None
+    for _ in range(args.steps):
+        img, st = step()
+        kernel_ms.append(st["kernel_ms"])
+        rays_local = st["rays"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    rays_frame = float(r.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    mrays = rays_frame * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        # ---- roofline: reference-visit-set bytes per ray from the counting kernel on a spp=8 slice ----
+        render.traversal = crt.TRAVERSAL_REFERENCE
+        render.set_spp(8)
+        render.run_view(eye, inv_view, fov, stats=True, want_mean=False, width=args.width, height=args.height)
+        s = render.stats
+        b_ray = (64.0 * s["inner_pops"] + 8.0 * s["leaf_pops"] + 36.0 * s["tri_tests"] + 16.0 * s["hits"]) / s["rays"]
+        k_ms = float(np.mean(kernel_ms))
+        rays_launch = float(rays_local)  # rank 0's launch
+        achieved = rays_launch * b_ray / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "kernel": "k_paths", "kernel_ms": round(k_ms, 3), "bytes_per_ray": round(b_ray, 1),
+                    "rays_per_launch": int(rays_launch)}
+        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+        if os.path.exists(traffic_file):
+            try:
+                roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+            except Exception:
+                pass
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib as O
+            osc = O.OracleScene(task.OBJ_paths, task.bvh_thresh_n)
+            c0 = time.perf_counter()
+            _, _, _, ost = osc.render(eye, inv_view, fov, args.width, args.height, args.cpu_spp, task.P_RR,
+                                      task.light_sample_n, seed=args.seed)
+            cdt = time.perf_counter() - c0
+            cpu = {"value": round(ost["rays"] / cdt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                   "sample": "%s %dx%d spp=%d (%d paths, %d rays) in %.1f s, single thread"
+                             % (args.scene, args.width, args.height, args.cpu_spp, ost["paths"], ost["rays"], cdt),
+                   "ms_per_frame_extrapolated": round(cdt * 1e3 * args.spp / args.cpu_spp, 1)}
+        if args.save_png:
+            from PIL import Image
+            Image.fromarray(img.cpu().numpy()).save(args.save_png)
+        line = {
+            "metric": "Mrays/sec", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d spp=%d P_RR=%g light_sample_n=%d (stand-in cornell-box.obj, 40972 triangles)"
+                                   % (args.scene, args.width, args.height, args.spp, float(task.P_RR), task.light_sample_n)
+                       if args.scene == "cornell-box" else
+                       "%s %dx%d spp=%d P_RR=%g light_sample_n=%d" % (args.scene, args.width, args.height, args.spp,
+                                                                      float(task.P_RR), task.light_sample_n),
+                       "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % world, "seed": args.seed},
+            "frames_per_sec": round(1e3 / ms_per_step, 4),
+            "rays_per_frame": int(rays_frame),
+            "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    render.free()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

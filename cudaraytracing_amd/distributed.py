@@ -44,6 +44,21 @@ def untile_torch(gathered, width, height):
     return a[:height, :width].contiguous()
 
 
+def _check_single_hip_runtime():
+    """torch bundles its own libamdhip64.so.7; libcrt.so links the system one.  The loader
+    shares one copy only if torch is imported BEFORE libcrt.so is loaded (it matches the
+    request against the SONAME of what is already mapped).  Two HIP runtimes in one process
+    cannot see each other's allocations, so refuse to continue."""
+    paths = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                paths.add(line.split()[-1])
+    if len(paths) > 1:
+        raise RuntimeError("two HIP runtimes are mapped (%s): import torch before using cudaraytracing_amd"
+                           % ", ".join(sorted(paths)))
+
+
 def render_sharded(render, eye, inv_view, fov_y, width, height, rank, world, device, group=None, want_stats=True):
     """One process per GPU: renders this rank's tiles into a torch uint8 tensor, all-gathers
     the compact buffers over RCCL (torch.distributed backend "nccl") and returns
@@ -51,6 +66,8 @@ def render_sharded(render, eye, inv_view, fov_y, width, height, rank, world, dev
     import torch
     import torch.distributed as dist
     from .api import shard_slots
+
+    _check_single_hip_runtime()
 
     slots = shard_slots(width, height, rank, world)
     local = torch.empty((slots, 3), dtype=torch.uint8, device=device)
