@@ -2,29 +2,38 @@
 //
 // Hand-written HIP for gfx950 (MI355X).  Replaces the reference's
 // view_render_kernel / cast_ray_v2 / DeviceBVH::intersect
-// (include/Render.cuh:199-354, include/DeviceBVH.cuh:87-170) with:
+// (include/Render.cuh:199-354, include/DeviceBVH.cuh:87-170).
 //
-//   k_paths       one work item = one (pixel, sample) path.  Work items are
-//                 ordered tile-major so the 64 lanes of a wave start on one 8x8
-//                 pixel tile.  Every random draw is addressed explicitly
-//                 (Philox counter = sample/depth/purpose/index, crt_detmath.h),
-//                 which lets next-event estimation run in the forward pass while
-//                 the radiance recursion is still evaluated deepest-vertex-first
-//                 in the reference's float order (Render.cuh:238-326).  The
-//                 reference's 7.7 KB/pixel global bounce stack becomes a 20 B
-//                 per-vertex record; its 1 KB/pixel BVH stack lives in LDS.
+// The reference runs one thread per pixel through the whole spp loop; measured
+// on MI355X that shape keeps only ~14 % of the lanes busy (paths end at
+// different depths, rays at different node counts).  This build is a wavefront
+// path tracer instead, with the path state resident in HBM (MI355X has the
+// capacity and bandwidth to trade ~200 B of streaming per ray for full waves):
+//
+//   pool          N path slots (structure-of-arrays float4 planes, coalesced).
+//   k_logic       one thread per slot: consumes the result of the slot's last
+//                 ray, advances the path (hit processing, next-event sampling,
+//                 Russian roulette, regeneration of finished paths from a global
+//                 work counter) until it needs another ray, and writes that ray.
+//   k_trace       one ray per slot: LDS-stack BVH traversal, writes (t, tri).
 //   k_accumulate  per pixel, sums L_k / spp in sample order (Render.cuh:348),
-//                 tone-maps (Render.cuh:350) and writes RGB8 + float mean.
+//                 tone-maps (Render.cuh:350), writes RGB8 + float mean.
 //
-// Results are bit-identical to the CPU oracle (oracle/crt_oracle.cpp).
-// Build: -ffp-contract=off, correctly rounded fp32 divide/sqrt (see build.py).
+// Every random draw is addressed explicitly (Philox counter = sample / depth /
+// purpose / index, crt_detmath.h), so next-event estimation runs when a vertex
+// is found while the radiance recursion is still evaluated deepest-vertex-first
+// in the reference's float order (Render.cuh:238-326) from 32 B per-vertex
+// records.  Results are bit-identical to the CPU oracle (oracle/crt_oracle.cpp).
+// Build: -ffp-contract=off, correctly rounded fp32 divide/sqrt (build.py).
 #include "../../include/crt.h"
 #include "crt_device.h"
+#include "crt_trace.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,443 +44,472 @@ extern "C" void crt_set_last_error_(const char* msg);
 
 namespace {
 
-enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_COUNT };
+// Statistics counters are sharded over CNT_SHARDS cache lines (16 x u64 each): thousands of
+// atomics per launch on ONE address serialise at the memory side (~12 ns each) and cost more
+// than the kernel itself.  The host sums the shards.
+enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_COUNT };
+#define CNT_SHARDS 256
+#define CNT_STRIDE 16
+// The work-item cursor is sharded too: shard s hands out items [s*per, (s+1)*per); a wave
+// starts at its home shard and moves on when a shard is exhausted.
+#define ITEM_SHARDS 64
+#define ITEM_STRIDE 32 /* u32 per shard = one 128 B line */
 
-struct KParams {
+enum { ST_DEAD = 0, ST_NEW = 1, ST_HIT = 2, ST_PROBE = 3, ST_SHADOW = 4 };
+enum { RAY_NONE = 0, RAY_CLOSEST = 1, RAY_SHADOW = 2 };
+#define ITEM_NONE 0xffffffffu
+
+// Path pool, structure of arrays; every plane has `n` entries.
+struct Pool {
+    float4* ro;   // ray origin.xyz, t_limit (shadow rays: Render.cuh:272)
+    float4* rd;   // ray direction.xyz (normalised as Ray does), bits(ray kind)
+    float4* vx;   // current vertex position.xyz, bits(triangle)
+    float4* la;   // next-event accumulator L_dir.xyz of the current vertex, bits(depth | stage << 8 | sample << 16)
+    float4* cc;   // contribution of the in-flight shadow ray .xyz, bits(work item)
+    float2* res;  // result of the slot's last ray: t, bits(triangle or -1)
+    float4* rec_a; // [depth][n]: L_dir.xyz of that vertex, cos to the next vertex
+    float4* rec_b; // [depth][n]: incoming direction.xyz, bits(triangle)
+    uint32_t n;
+};
+
+struct LParams {
     DevScene sc;
+    Pool pool;
     float eye[3];
     float inv_view[9];
     float scale, ar;
-    uint32_t width, height, spp;
+    uint32_t width, height;
     float p_rr;
     int32_t lsn;
     uint64_t seed;
     uint32_t rank, world, tiles_x, n_tiles;
     uint32_t nslots;        // pixel slots of this shard (local tiles * 64)
     uint32_t sample_begin;  // first sample index of this chunk
-    uint64_t n_items;       // nslots * samples in this chunk
-    float* L;               // 3 planes of `plane` floats
-    uint64_t plane;
+    uint32_t n_items;       // nslots * samples in this chunk
+    uint32_t items_per_shard;
+    unsigned int* item_next; // [ITEM_SHARDS * ITEM_STRIDE] cursors, relative to the shard start
+    float4* L;              // per work item radiance
+    unsigned long long* counters;
+};
+
+struct TParams {
+    DevScene sc;
+    Pool pool;
     unsigned long long* counters;
     int32_t stack_cap;
 };
 
-struct Counters {
-    uint32_t rays, shadow, probe, inner, leaf, tests, hits;
-};
-
-// slot -> pixel.  Returns false for padding slots (ragged image edge / tile beyond the image).
-__device__ __forceinline__ bool slot_to_pixel(const KParams& P, uint32_t slot, uint32_t& i, uint32_t& j)
+// work item slot -> pixel.  false for padding slots (ragged image edge / tile beyond the image).
+__device__ __forceinline__ bool slot_to_pixel(uint32_t slot, uint32_t rank, uint32_t world, uint32_t n_tiles, uint32_t tiles_x,
+                                              uint32_t width, uint32_t height, uint32_t& i, uint32_t& j)
 {
-    uint32_t tile = (slot >> 6) * P.world + P.rank;
+    uint32_t tile = (slot >> 6) * world + rank;
     uint32_t pix = slot & 63u;
-    if (tile >= P.n_tiles) return false;
-    uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    if (tile >= n_tiles) return false;
+    uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
     i = tx * CRT_TILE + (pix & 7u);
     j = ty * CRT_TILE + (pix >> 3);
-    return i < P.width && j < P.height;
+    return i < width && j < height;
 }
 
-// ---------------------------------------------------------------------------
-// BVH traversal.
-//
-// Reference semantics (DeviceBVH.cuh:128-170, :31-43, DeviceTriangle.cuh:39-65):
-// every node whose box passes hit_AABB is visited (no pruning, the root box is
-// never tested), right child first; a leaf keeps its first triangle among equal
-// t (strict <), and an earlier-visited leaf wins equal t.  Leaves are therefore
-// visited in DESCENDING order of their first-triangle index, so the winner among
-// equal-t candidates is "largest leaf start, then smallest triangle index".
-// Encoding that rule explicitly makes the result independent of visit order,
-// which is what allows the FAST mode (near-first order, pruning of boxes that
-// start beyond the current best by a conservative margin, any-hit exit for
-// shadow rays) to return exactly what the exhaustive REFERENCE mode returns.
-// ---------------------------------------------------------------------------
-struct Hit {
-    float t;
-    int32_t tri;      // BVH-order triangle index, -1 = miss
-    int32_t leaf_it;  // first triangle of the leaf that produced it
+// Takes the next work item for every lane that is active here with ONE atomic per wave and
+// shard (ballot of the active lanes, the first one adds their count, prefix rank per lane).
+__device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, unsigned int* item_next, uint32_t per, uint32_t n_items,
+                                              uint32_t home)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t item = ITEM_NONE;
+    for (uint32_t t = 0; t < ITEM_SHARDS; t++) {
+        const uint32_t sh = (home + t) & (ITEM_SHARDS - 1);
+        const uint32_t lo = sh * per;
+        if (lo >= n_items) continue;
+        const uint32_t hi = min(lo + per, n_items);
+        unsigned int* cur = item_next + sh * ITEM_STRIDE;
+        // cursors only grow, so a stale read can at worst cost one fruitless atomic
+        if (lo + __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi) continue;
+        const unsigned long long mask = __ballot(1);
+        const int leader = __ffsll((long long)mask) - 1;
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(cur, (unsigned int)__popcll(mask));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base); // leader is the first active lane
+        const unsigned long long idx = (unsigned long long)lo + base + rank;
+        if (idx < hi) { item = (uint32_t)idx; break; }
+    }
+    return item;
+}
+
+// ---------------------------------------------------------------- logic ----
+struct PathCounters {
+    uint32_t rays, shadow, probe, paths;
 };
 
-// reference: DeviceBVH.cuh:87-126.  nx/ny/nz = dir component < 0 (the swap).
-__device__ __forceinline__ bool slab_test(float4 lo, float4 hi, const RayT& r, bool nx, bool ny, bool nz, float& t_enter)
+struct Lane {
+    F3 ro, rd, pos, Ld, c;
+    float tl;
+    uint32_t kind, vtri, depth, stage, q, item;
+    uint32_t pixel_index, k;
+};
+
+__device__ __forceinline__ void decode_item(const LParams& P, uint32_t item, uint32_t& pixel_index, uint32_t& k, bool& valid,
+                                            uint32_t& pi, uint32_t& pj)
 {
-    float tx0 = ((nx ? hi.x : lo.x) - r.o.x) * r.inv.x;
-    float tx1 = ((nx ? lo.x : hi.x) - r.o.x) * r.inv.x;
-    float ty0 = ((ny ? hi.y : lo.y) - r.o.y) * r.inv.y;
-    float ty1 = ((ny ? lo.y : hi.y) - r.o.y) * r.inv.y;
-    float tz0 = ((nz ? hi.z : lo.z) - r.o.z) * r.inv.z;
-    float tz1 = ((nz ? lo.z : hi.z) - r.o.z) * r.inv.z;
-    t_enter = maxf_ref(maxf_ref(tx0, ty0), tz0);
-    float t_exit = minf_ref(minf_ref(tx1, ty1), tz1);
-    return t_enter <= t_exit + CRT_EPSILON && t_exit >= 0;
+    uint32_t s = item / P.nslots;
+    uint32_t slot = item - s * P.nslots;
+    k = P.sample_begin + s;
+    valid = slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.width, P.height, pi, pj);
+    pixel_index = pj * P.width + pi; // Render.cuh:336
 }
 
-// conservative pruning bound: a box may be skipped only if it starts beyond this
-__device__ __forceinline__ float prune_bound(float t) { return t + (absf(t) * 1.0e-3f + 1.0e-3f); }
-
-// MODE: 0 = FAST, 1 = REFERENCE.  ANY: shadow query "exists valid hit with t_limit - t > EPSILON"
-// (equivalent to the reference's closest-hit test in blocked(), Render.cuh:19-27, because float
-// subtraction is monotone); returns hit.tri >= 0 iff blocked.
-template <int MODE, bool ANY, bool STATS>
-__device__ __forceinline__ Hit trace(const DevScene& sc, const RayT& r, float t_limit, int* stack, float* tstack, int lane_stride,
-                                     Counters& cnt)
+// Sets up next-event sample q of the current vertex: Render.cuh:262-272 (+ :274-283 evaluated
+// ahead of the visibility test; the value is only added if the shadow ray is not blocked).
+__device__ __forceinline__ void setup_shadow(const LParams& P, Lane& s, F3 nrm, F3 f_r)
 {
-    Hit best;
-    best.t = FLT_MAX; best.tri = -1; best.leaf_it = -1;
-    const bool nx = r.d.x < 0, ny = r.d.y < 0, nz = r.d.z < 0;
-    int sp = 0;
-    int ref = sc.root_ref;
-    float ref_t = -FLT_MAX;
-    bool have = true;
-    // shadow-ray pruning bound is fixed; closest-hit bound shrinks with best.t
-    float bound = ANY ? prune_bound(t_limit) : FLT_MAX;
-    if (ANY && MODE == 0) {
-        // NaN or -inf limit can never be "blocked"; +inf is blocked by any hit (bound = inf)
-        if (!(t_limit == t_limit) || t_limit == -pinf()) return best;
+    const DevScene& sc = P.sc;
+    uint32_t li = s.q / (uint32_t)P.lsn, sj = s.q - li * (uint32_t)P.lsn;
+    uint2 lg = sc.lights[li];
+    U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, li * (uint32_t)P.lsn + sj);
+    uint32_t ti = rl.x % lg.y; // DeviceLights.cuh:35
+    const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
+    float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3];
+    float alpha = rng_uniform(rl.y); // DeviceTriangle.cuh:69-71
+    float beta = rng_uniform(rl.z) * (1 - alpha);
+    float gamma = 1 - alpha - beta;
+    F3 lv1 = f3(l0.x, l0.y, l0.z), lv2 = f3(l0.w, l1.x, l1.y), lv3 = f3(l1.z, l1.w, l2.x);
+    F3 lpos = add3(add3(scalel3(alpha, lv1), scalel3(beta, lv2)), scalel3(gamma, lv3));
+    F3 dist = sub3(lpos, s.pos);
+    F3 dir = unit3(dist);
+    s.ro = s.pos;
+    s.rd = unit3(dir);     // Ray normalises again (Ray.cuh:13)
+    s.tl = dist.x / dir.x; // Render.cuh:272
+    s.kind = RAY_SHADOW;
+    float tl = norm3(dist);
+    float t2 = tl * tl;
+    float cos_theta = dot3(dir, nrm);
+    float cos_theta_2 = -dot3(dir, f3(l2.y, l2.z, l2.w));
+    cos_theta = cos_theta > 0.0f ? cos_theta : 0.0f;
+    cos_theta_2 = cos_theta_2 > 0.0f ? cos_theta_2 : 0.0f;
+    // ((((Le*fr)*cos)*cos2)*inv_pdf)/t2)/lsn  (Render.cuh:283)
+    F3 c = mul3(f3(l3.x, l3.y, l3.z), f_r);
+    c = scale3(c, cos_theta);
+    c = scale3(c, cos_theta_2);
+    c = scale3(c, l3.w);
+    c = div3(c, t2);
+    c = div3(c, (float)P.lsn);
+    s.c = c;
+}
+
+// Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
+__device__ __forceinline__ F3 finish_path(const LParams& P, uint32_t slot, int deepest, bool emissive, F3 ke)
+{
+    const DevScene& sc = P.sc;
+    const Pool& pl = P.pool;
+    F3 L = f3(0.0f, 0.0f, 0.0f);
+    if (deepest < 0) return L;
+    const float inv_pdf_sphere = (float)(2.0f * 3.14159265358979323846); // Global.h:96-99
+    if (emissive) {
+        L = deepest == 0 ? add3(f3(0.0f, 0.0f, 0.0f), ke) : f3(0.0f, 0.0f, 0.0f); // :249-255, :323
+    } else {
+        float4 a = pl.rec_a[(size_t)deepest * pl.n + slot];
+        L = add3(f3(0.0f, 0.0f, 0.0f), f3(a.x, a.y, a.z)); // final hit: direct light only (:316-319)
     }
-    while (true) {
-        if (!have) {
-            if (sp == 0) break;
-            sp--;
-            ref = stack[sp * lane_stride];
-            if (MODE == 0) {
-                ref_t = tstack[sp * lane_stride];
-                if (ref_t > bound) continue; // pruned after a closer hit was found
-            }
+    for (int v = deepest - 1; v >= 0; v--) {
+        float4 a = pl.rec_a[(size_t)v * pl.n + slot];
+        int tri = __float_as_int(pl.rec_b[(size_t)v * pl.n + slot].w);
+        float4 fm = sc.mats[sc.tri_mat[tri] * 3 + 0];
+        F3 ind = mul3(L, f3(fm.x, fm.y, fm.z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
+        ind = scale3(ind, a.w);
+        ind = scale3(ind, inv_pdf_sphere);
+        ind = div3(ind, P.p_rr);
+        L = add3(ind, f3(a.x, a.y, a.z)); // :323
+    }
+    return L;
+}
+
+// One pass per round, phases in the order every possible chain runs through them
+// (result -> enter vertex -> roulette/bounce -> finish -> regenerate -> next-event setup), so a
+// wave executes each phase at most once however its lanes are distributed over path stages.
+__global__ __launch_bounds__(256) void k_logic(const LParams P)
+{
+    const DevScene& sc = P.sc;
+    const Pool& pl = P.pool;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t s_cnt[5];
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    PathCounters cnt;
+    cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
+    bool emitted = false;
+    uint32_t stage = ST_DEAD, depth = 0, q = 0;
+    float4 la = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (slot < pl.n) {
+        la = pl.la[slot];
+        uint32_t st = __float_as_uint(la.w);
+        depth = st & 255u; stage = (st >> 8) & 15u; q = st >> 16;
+    }
+    if (stage != ST_DEAD) {
+        Lane s;
+        s.depth = depth; s.stage = stage; s.q = q;
+        s.Ld = f3(la.x, la.y, la.z);
+        s.kind = RAY_NONE;
+        s.pixel_index = 0; s.k = 0; s.item = ITEM_NONE;
+        s.c = s.pos = s.ro = s.rd = f3(0.0f, 0.0f, 0.0f);
+        s.tl = 0.0f; s.vtri = 0;
+        float res_t = FLT_MAX;
+        int res_tri = -1;
+        if (stage != ST_NEW) {
+            float4 cc = pl.cc[slot];
+            s.c = f3(cc.x, cc.y, cc.z); s.item = __float_as_uint(cc.w);
+            float4 vx = pl.vx[slot];
+            s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
+            float4 ro = pl.ro[slot], rd = pl.rd[slot];
+            s.ro = f3(ro.x, ro.y, ro.z); s.tl = ro.w;
+            s.rd = f3(rd.x, rd.y, rd.z);
+            float2 rs = pl.res[slot];
+            res_t = rs.x;
+            res_tri = __float_as_int(rs.y);
+            bool v; uint32_t pi, pj;
+            decode_item(P, s.item, s.pixel_index, s.k, v, pi, pj);
         }
-        have = false;
-        if (ref >= 0) {
-            if (STATS) cnt.inner++;
-            const float4* n = sc.nodes + (size_t)ref * 4;
-            float4 a = n[0], b = n[1], c = n[2], d = n[3];
-            float tl, tr;
-            bool hl = slab_test(a, b, r, nx, ny, nz, tl);
-            bool hr = slab_test(c, d, r, nx, ny, nz, tr);
-            int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-            if (MODE == 1) {
-                // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
-                if (hl && hr) { stack[sp * lane_stride] = lref; sp++; ref = rref; have = true; }
-                else if (hl) { ref = lref; have = true; }
-                else if (hr) { ref = rref; have = true; }
+        bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
+        int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
+
+        // ---- phase 1: consume the result of the slot's last ray ----
+        if (stage == ST_SHADOW) {
+            // visibility of next-event sample q (Render.cuh:19-27, :272-284)
+            bool blocked = s.tl - res_t > CRT_EPSILON;
+            if (!blocked) s.Ld = add3(s.Ld, s.c);
+            s.q++;
+            if (s.q < (uint32_t)(sc.n_lights * P.lsn)) do_shadow_setup = true; else do_nee_done = true;
+        } else if (stage == ST_HIT) {
+            // the camera / bounce ray that looked for vertex `depth` (Render.cuh:207-213)
+            if (res_tri < 0) {
+                fin_deepest = (int)s.depth - 1; fin_emissive = false;
+                do_finish = true;
             } else {
-                hl = hl && !(tl > bound);
-                hr = hr && !(tr > bound);
-                if (hl && hr) {
-                    bool left_first = tl <= tr;
-                    int far_ref = left_first ? rref : lref;
-                    float far_t = left_first ? tr : tl;
-                    stack[sp * lane_stride] = far_ref;
-                    tstack[sp * lane_stride] = far_t;
-                    sp++;
-                    ref = left_first ? lref : rref;
-                    have = true;
-                } else if (hl) { ref = lref; have = true; }
-                else if (hr) { ref = rref; have = true; }
-            }
-        } else {
-            if (STATS) cnt.leaf++;
-            uint32_t code = (uint32_t)~ref;
-            int it = (int)(code >> 4);
-            int n = (int)(code & 15u);
-            if (n == 0) n = sc.leaf_count[it];
-            for (int i = it; i < it + n; i++) {
-                if (STATS) cnt.tests++;
-                const float4* g = sc.tri_geo + (size_t)i * 3;
-                float4 A = g[0], B = g[1], C = g[2];
-                F3 v1 = f3(A.x, A.y, A.z), e1 = f3(A.w, B.x, B.y), e2 = f3(B.z, B.w, C.x);
-                // Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56
-                F3 s = sub3(r.o, v1);
-                F3 s1 = cross3(r.d, e2);
-                F3 s2 = cross3(s, e1);
-                float reciprocal = 1 / dot3(s1, e1);
-                float beta = dot3(s1, s) * reciprocal;
-                float gamma = dot3(s2, r.d) * reciprocal;
-                float t = dot3(s2, e2) * reciprocal;
-                float alpha = 1 - beta - gamma;
-                bool inside = 0 < alpha && alpha < 1 && 0 < beta && beta < 1 && 0 < gamma && gamma < 1; // :58-65
-                if (inside && t > CRT_EPSILON) { // DeviceBVH.cuh:37
-                    if (ANY) {
-                        if (t_limit - t > CRT_EPSILON) { best.t = t; best.tri = i; best.leaf_it = it; return best; }
-                    } else if (t < best.t || (t == best.t && it > best.leaf_it)) {
-                        best.t = t; best.tri = i; best.leaf_it = it;
-                        if (MODE == 0) bound = prune_bound(t);
+                F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
+                pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __int_as_float(res_tri));
+                do_enter = true;
+                if (s.depth > 0) {
+                    // the previous vertex is not the deepest one: cosine of its indirect term (Render.cuh:291)
+                    const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
+                    float4 pb = pl.rec_b[pr];
+                    int ptri = __float_as_int(pb.w);
+                    float4 pg = sc.tri_geo[(size_t)ptri * 3 + 2];
+                    F3 pn = f3(pg.y, pg.z, pg.w);
+                    float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
+                    cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
+                    pl.rec_a[pr].w = cos_prev;
+                    int pmat = sc.tri_mat[ptri];
+                    float4 pm1 = sc.mats[pmat * 3 + 1];
+                    if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
+                        float ns = sc.mats[pmat * 3 + 0].w;
+                        float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
+                        F3 in = unit3(f3(pb.x, pb.y, pb.z));
+                        F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
+                        float d_theta = (float)((double)(delta_coeff * 30) * 3.14159265358979323846 / 180);
+                        float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
+                        U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
+                        F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
+                        s.rd = unit3(refd); // Ray.cuh:13 (origin stays prev.pos)
+                        s.tl = 0.0f; s.kind = RAY_CLOSEST;
+                        s.stage = ST_PROBE;
+                        cnt.rays++; cnt.probe++;
+                        emitted = true;
+                        do_enter = false;
                     }
+                }
+                s.pos = pos; s.vtri = (uint32_t)res_tri;
+            }
+        } else if (stage == ST_PROBE) {
+            // the probe ray of vertex depth-1 (Render.cuh:304-313)
+            if (res_tri >= 0) {
+                int hmat = sc.tri_mat[res_tri];
+                float4 q1 = sc.mats[hmat * 3 + 1];
+                if (__float_as_uint(q1.w) & 1u) {
+                    float4 q2 = sc.mats[hmat * 3 + 2];
+                    const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
+                    int ptri = __float_as_int(pl.rec_b[pr].w);
+                    float4 pg = sc.tri_geo[(size_t)ptri * 3 + 2];
+                    F3 pn = f3(pg.y, pg.z, pg.w);
+                    int pmat = sc.tri_mat[ptri];
+                    float4 pm0 = sc.mats[pmat * 3 + 0], pm1 = sc.mats[pmat * 3 + 1];
+                    float log_shininess = det_log10f(pm0.w);
+                    float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
+                    float ip = (float)(2.0f * 3.14159265358979323846) / 8.f;
+                    F3 hp = add3(s.ro, scalel3(res_t, s.rd));
+                    float ct = dot3(unit3(sub3(hp, s.ro)), pn); // probe origin == prev.pos
+                    ct = ct > 0.0f ? ct : 0.0f;
+                    // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
+                    F3 kekd = mul3(f3(q2.x, q2.y, q2.z), f3(pm1.x, pm1.y, pm1.z));
+                    F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
+                    float4 a = pl.rec_a[pr];
+                    a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
+                    pl.rec_a[pr] = a;
+                }
+            }
+            do_enter = true;
+        }
+
+        // ---- phase 2: a new vertex (pos, vtri) at `depth` ----
+        F3 nrm = f3(0.0f, 0.0f, 0.0f), f_r = f3(0.0f, 0.0f, 0.0f);
+        if (do_enter || do_shadow_setup || do_nee_done) {
+            float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
+            nrm = f3(g.y, g.z, g.w);
+        }
+        if (do_enter || do_shadow_setup) {
+            int mat = sc.tri_mat[s.vtri];
+            float4 m0 = sc.mats[mat * 3 + 0];
+            f_r = f3(m0.x, m0.y, m0.z);
+            if (do_enter) {
+                float4 m1 = sc.mats[mat * 3 + 1];
+                if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+                    float4 m2 = sc.mats[mat * 3 + 2];
+                    fin_deepest = (int)s.depth; fin_emissive = true; fin_ke = f3(m2.x, m2.y, m2.z);
+                    do_finish = true;
+                } else {
+                    s.Ld = f3(0.0f, 0.0f, 0.0f);
+                    s.q = 0;
+                    if (sc.n_lights * P.lsn > 0) do_shadow_setup = true; else do_nee_done = true;
                 }
             }
         }
+
+        // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
+        if (do_nee_done) {
+            pl.rec_a[(size_t)s.depth * pl.n + slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, 0.0f);
+            bool stop = s.depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
+            U4 rb;
+            rb.x = rb.y = rb.z = rb.w = 0;
+            if (!stop) {
+                rb = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_BOUNCE, 0);
+                stop = rng_uniform(rb.x) > P.p_rr;
+            }
+            if (stop) {
+                fin_deepest = (int)s.depth; fin_emissive = false;
+                do_finish = true;
+            } else {
+                F3 ndir = unit3(sample_hemisphere(nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
+                s.ro = s.pos;
+                s.rd = unit3(ndir); // Ray.cuh:13
+                s.tl = 0.0f; s.kind = RAY_CLOSEST;
+                s.depth++;
+                s.stage = ST_HIT;
+                cnt.rays++;
+                emitted = true;
+            }
+        }
+
+        // ---- phase 4: path complete ----
+        if (do_finish) {
+            F3 L = finish_path(P, slot, fin_deepest, fin_emissive, fin_ke);
+            P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
+            do_new = true; // regenerate in place
+        }
+
+        // ---- phase 5: take the next work item, camera ray (Render.cuh:344-347) ----
+        if (do_new) {
+            s.stage = ST_DEAD;
+            for (;;) {
+                s.item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, (blockIdx.x * 4u + (threadIdx.x >> 6)) & (ITEM_SHARDS - 1));
+                if (s.item == ITEM_NONE) break;
+                bool valid; uint32_t pi, pj;
+                decode_item(P, s.item, s.pixel_index, s.k, valid, pi, pj);
+                if (!valid) continue; // padding slot of a ragged tile: take another item
+                cnt.paths++;
+                U4 rj = rng_draw(P.seed, s.pixel_index, s.k, 0, RNG_JITTER, 0);
+                float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
+                float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
+                F3 cd = unit3(f3(-x, y, 1));
+                F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
+                           P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
+                           P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
+                s.ro = f3(P.eye[0], P.eye[1], P.eye[2]);
+                s.rd = unit3(wd); // Ray.cuh:13
+                s.tl = 0.0f; s.kind = RAY_CLOSEST;
+                s.depth = 0; s.stage = ST_HIT; s.q = 0;
+                cnt.rays++;
+                emitted = true;
+                break;
+            }
+        }
+
+        // ---- phase 6: next-event sample q of the current vertex ----
+        if (do_shadow_setup) {
+            setup_shadow(P, s, nrm, f_r);
+            s.stage = ST_SHADOW;
+            cnt.rays++; cnt.shadow++;
+            emitted = true;
+        }
+
+        // ---- write the slot back ----
+        uint32_t st = s.depth | (s.stage << 8) | (s.q << 16);
+        pl.la[slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(st));
+        if (emitted) {
+            pl.cc[slot] = make_float4(s.c.x, s.c.y, s.c.z, __uint_as_float(s.item));
+            pl.vx[slot] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
+            pl.ro[slot] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.tl);
+            pl.rd[slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.kind));
+        } else {
+            pl.rd[slot].w = __uint_as_float((uint32_t)RAY_NONE);
+        }
     }
-    if (STATS && best.tri >= 0) cnt.hits++;
-    return best;
-}
-
-// ------------------------------------------------------------- samplers ----
-// reference: include/Global.h:35-50
-__device__ __forceinline__ F3 to_world(F3 a, F3 N)
-{
-    F3 C;
-    if (absf(N.x) > absf(N.y)) {
-        float invLen = 1.0f / sqrt_f(N.x * N.x + N.z * N.z);
-        C = f3(N.z * invLen, 0.0f, -N.x * invLen);
-    } else {
-        float invLen = 1.0f / sqrt_f(N.y * N.y + N.z * N.z);
-        C = f3(0.0f, N.z * invLen, -N.y * invLen);
+    // ---- counters: wave sums -> LDS -> one atomic per block and counter, on this block's shard ----
+    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
+    uint32_t al = wave_sum(emitted ? 1u : 0u);
+    if ((threadIdx.x & 63) == 0 && (r | pa | al)) {
+        atomicAdd(&s_cnt[0], r); atomicAdd(&s_cnt[1], sh); atomicAdd(&s_cnt[2], pr); atomicAdd(&s_cnt[3], pa); atomicAdd(&s_cnt[4], al);
     }
-    F3 B = cross3(C, N);
-    return add3(add3(scalel3(a.x, B), scalel3(a.y, C)), scalel3(a.z, N));
-}
-// reference: include/Global.h:57-66
-__device__ __forceinline__ F3 sample_hemisphere(F3 N, float x_1, float x_2)
-{
-    float z = absf(1.0f - 2.0f * x_1);
-    float r = sqrt_f(1.0f - z * z);
-    float phi = (float)(2 * 3.14159265358979323846 * (double)x_2);
-    float sn, cs;
-    det_sincosf(phi, &sn, &cs);
-    return to_world(f3(r * cs, r * sn, z), N);
-}
-// reference: include/Global.h:68-94
-__device__ __forceinline__ F3 sample_lobe(F3 out, float delta_theta, float delta_phi, float u1, float u2)
-{
-    float eta_1 = 2 * u1 - 1;
-    float eta_2 = 2 * u2 - 1;
-    float r = norm3(out);
-    float theta_0 = det_acosf(out.z / r);
-    float phi_0;
-    if ((double)absf(out.x) < 1e-5)
-        phi_0 = out.y > 0.0f ? (float)1.57079632679489661923 : -(float)1.57079632679489661923;
-    else
-        phi_0 = det_atan2f(out.y, out.x);
-    float theta = theta_0 + eta_1 * delta_theta;
-    float phi = phi_0 + eta_2 * delta_phi;
-    float st, ct, sp, cp;
-    det_sincosf(theta, &st, &ct);
-    det_sincosf(phi, &sp, &cp);
-    return f3(st * cp, st * sp, ct);
+    __syncthreads();
+    if (threadIdx.x < 5 && s_cnt[threadIdx.x]) {
+        const int idx[5] = {C_RAYS, C_SHADOW, C_PROBE, C_PATHS, C_ALIVE};
+        atomicAdd(&P.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + idx[threadIdx.x]], (unsigned long long)s_cnt[threadIdx.x]);
+    }
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+__global__ __launch_bounds__(256) void k_pool_init(Pool pl)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= pl.n) return;
+    pl.la[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_NEW << 8));
+    pl.rd[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)RAY_NONE));
+    pl.res[slot] = make_float2(FLT_MAX, __int_as_float(-1));
 }
 
-// ---------------------------------------------------------------- paths ----
-struct Vertex {          // what the next step needs to know about the previous vertex
-    F3 pos, n, from_dir, Ldir;
-    int32_t mat;
-};
-
+// ---------------------------------------------------------------- trace ----
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(256) void k_paths(const KParams P)
+__global__ __launch_bounds__(256) void k_trace(const TParams T)
 {
     extern __shared__ int s_lds[];
     const int tid = threadIdx.x;
     int* stack = s_lds + tid;
-    float* tstack = reinterpret_cast<float*>(s_lds + 256 * P.stack_cap) + tid;
-    const DevScene& sc = P.sc;
-
-    Counters cnt;
-    cnt.rays = cnt.shadow = cnt.probe = cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
-
-    const uint64_t item = (uint64_t)blockIdx.x * 256u + (uint64_t)tid;
-    uint32_t pi = 0, pj = 0;
-    bool live = item < P.n_items;
-    uint32_t slot = 0, s_in_chunk = 0;
-    if (live) {
-        s_in_chunk = (uint32_t)(item / P.nslots);
-        slot = (uint32_t)(item - (uint64_t)s_in_chunk * P.nslots);
-        live = slot_to_pixel(P, slot, pi, pj);
-    }
-    F3 L = f3(0.0f, 0.0f, 0.0f);
-    if (live) {
-        const uint32_t k = P.sample_begin + s_in_chunk;
-        const uint32_t pixel_index = pj * P.width + pi; // Render.cuh:336
-        const float inv_pdf_sphere = (float)(2.0f * 3.14159265358979323846); // Global.h:96-99
-        // ---- camera ray: Render.cuh:344-347 ----
-        U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
-        float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
-        float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
-        F3 cd = unit3(f3(-x, y, 1));
-        F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
-                   P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
-                   P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
-        RayT ray = make_ray(f3(P.eye[0], P.eye[1], P.eye[2]), wd);
-
-        // per-vertex records for the backward recursion
-        float h_r[CRT_BOUNCE_STACK_SIZE], h_g[CRT_BOUNCE_STACK_SIZE], h_b[CRT_BOUNCE_STACK_SIZE], h_cos[CRT_BOUNCE_STACK_SIZE];
-        int32_t h_mat[CRT_BOUNCE_STACK_SIZE];
-        int deepest = -1;           // deepest vertex that "happend"
-        bool deepest_emissive = false;
-        F3 deepest_ke = f3(0.0f, 0.0f, 0.0f);
-        Vertex prev;
-        prev.mat = 0;
-        prev.pos = prev.n = prev.from_dir = prev.Ldir = f3(0.0f, 0.0f, 0.0f);
-
-        // ---- forward walk: Render.cuh:205-230, with the per-vertex work of the backward loop
-        //      (NEE :262-286, probe :294-314) hoisted to where its inputs become known ----
-        for (int depth = 0;; depth++) {
-            cnt.rays++;
-            Hit hit = trace<MODE, false, STATS>(sc, ray, 0.0f, stack, tstack, 256, cnt);
-            if (hit.tri < 0) {
-                // vertex `depth` did not happen: the previous vertex is the final one (direct light only)
-                if (depth > 0) {
-                    h_r[depth - 1] = prev.Ldir.x; h_g[depth - 1] = prev.Ldir.y; h_b[depth - 1] = prev.Ldir.z;
-                    h_cos[depth - 1] = 0.0f; h_mat[depth - 1] = prev.mat;
-                    deepest = depth - 1;
-                }
-                break;
-            }
-            F3 pos = add3(ray.o, scalel3(hit.t, ray.d)); // DeviceTriangle.cuh:50
-            float4 gC = sc.tri_geo[(size_t)hit.tri * 3 + 2];
-            F3 nrm = f3(gC.y, gC.z, gC.w);
-            int32_t mat = sc.tri_mat[hit.tri];
-            float4 m0 = sc.mats[mat * 3 + 0], m1 = sc.mats[mat * 3 + 1];
-            uint32_t mflags = (uint32_t)__float_as_int(m1.w);
-
-            if (depth > 0) {
-                // previous vertex is not the deepest: it gets the indirect term and (SPECULAR) the probe
-                float cos_prev = dot3(unit3(sub3(pos, prev.pos)), prev.n); // Render.cuh:291
-                cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
-                float4 pm0 = sc.mats[prev.mat * 3 + 0], pm1 = sc.mats[prev.mat * 3 + 1];
-                if ((uint32_t)__float_as_int(pm1.w) & 2u) { // SPECULAR: Render.cuh:294-314
-                    float ns = pm0.w;
-                    float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
-                    F3 in = unit3(prev.from_dir);
-                    F3 out = sub3(in, scale3(prev.n, 2.f * dot3(in, prev.n)));
-                    float d_theta = (float)((double)(delta_coeff * 30) * 3.14159265358979323846 / 180);
-                    float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
-                    U4 rp = rng_draw(P.seed, pixel_index, k, (uint32_t)(depth - 1), RNG_PROBE, 0);
-                    F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
-                    RayT probe = make_ray(prev.pos, refd);
-                    cnt.rays++; cnt.probe++;
-                    Hit ph = trace<MODE, false, STATS>(sc, probe, 0.0f, stack, tstack, 256, cnt);
-                    if (ph.tri >= 0) {
-                        int32_t pmat = sc.tri_mat[ph.tri];
-                        float4 q1 = sc.mats[pmat * 3 + 1], q2 = sc.mats[pmat * 3 + 2];
-                        if ((uint32_t)__float_as_int(q1.w) & 1u) { // probe hit an emitter (:304)
-                            float log_shininess = det_log10f(ns);
-                            float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
-                            float ip = inv_pdf_sphere / 8.f;
-                            F3 hp = add3(probe.o, scalel3(ph.t, probe.d));
-                            float ct = dot3(unit3(sub3(hp, prev.pos)), prev.n);
-                            ct = ct > 0.0f ? ct : 0.0f;
-                            // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
-                            F3 kekd = mul3(f3(q2.x, q2.y, q2.z), f3(pm1.x, pm1.y, pm1.z));
-                            F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
-                            prev.Ldir = add3(prev.Ldir, temp);
-                        }
-                    }
-                }
-                h_r[depth - 1] = prev.Ldir.x; h_g[depth - 1] = prev.Ldir.y; h_b[depth - 1] = prev.Ldir.z;
-                h_cos[depth - 1] = cos_prev; h_mat[depth - 1] = prev.mat;
-            }
-            deepest = depth;
-            if (mflags & 1u) { // hit an emitter: path ends (:210); contributes only as camera vertex (:249-255)
-                deepest_emissive = true;
-                float4 m2 = sc.mats[mat * 3 + 2];
-                deepest_ke = f3(m2.x, m2.y, m2.z);
-                break;
-            }
-            // ---- next-event estimation at this vertex: Render.cuh:258-286 ----
-            F3 f_r = f3(m0.x, m0.y, m0.z);
-            F3 Ldir = f3(0.0f, 0.0f, 0.0f);
-            for (int li = 0; li < sc.n_lights; li++) {
-                uint2 lg = sc.lights[li];
-                for (int sj = 0; sj < P.lsn; sj++) {
-                    U4 rl = rng_draw(P.seed, pixel_index, k, (uint32_t)depth, RNG_NEE, (uint32_t)(li * P.lsn + sj));
-                    uint32_t ti = rl.x % lg.y; // DeviceLights.cuh:35
-                    const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
-                    float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3];
-                    float alpha = rng_uniform(rl.y);                 // DeviceTriangle.cuh:69-71
-                    float beta = rng_uniform(rl.z) * (1 - alpha);
-                    float gamma = 1 - alpha - beta;
-                    F3 lv1 = f3(l0.x, l0.y, l0.z), lv2 = f3(l0.w, l1.x, l1.y), lv3 = f3(l1.z, l1.w, l2.x);
-                    F3 lpos = add3(add3(scalel3(alpha, lv1), scalel3(beta, lv2)), scalel3(gamma, lv3));
-                    F3 dist = sub3(lpos, pos);
-                    F3 dir = unit3(dist);
-                    RayT back = make_ray(pos, dir);
-                    float t_to_light = dist.x / dir.x; // Render.cuh:272
-                    cnt.rays++; cnt.shadow++;
-                    bool blocked;
-                    if (MODE == 1) {
-                        Hit sh = trace<1, false, STATS>(sc, back, 0.0f, stack, tstack, 256, cnt);
-                        blocked = t_to_light - sh.t > CRT_EPSILON; // Render.cuh:22
-                    } else {
-                        Hit sh = trace<0, true, false>(sc, back, t_to_light, stack, tstack, 256, cnt);
-                        blocked = sh.tri >= 0;
-                    }
-                    if (!blocked) {
-                        float tl = norm3(dist);
-                        float t2 = tl * tl;
-                        float cos_theta = dot3(dir, nrm);
-                        float cos_theta_2 = -dot3(dir, f3(l2.y, l2.z, l2.w));
-                        cos_theta = cos_theta > 0.0f ? cos_theta : 0.0f;
-                        cos_theta_2 = cos_theta_2 > 0.0f ? cos_theta_2 : 0.0f;
-                        // ((((Le*fr)*cos)*cos2)*inv_pdf)/t2)/lsn  (:283)
-                        F3 c = mul3(f3(l3.x, l3.y, l3.z), f_r);
-                        c = scale3(c, cos_theta);
-                        c = scale3(c, cos_theta_2);
-                        c = scale3(c, l3.w);
-                        c = div3(c, t2);
-                        c = div3(c, (float)P.lsn);
-                        Ldir = add3(Ldir, c);
-                    }
-                }
-            }
-            // ---- continue or stop: Render.cuh:210-228 ----
-            bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
-            U4 rb;
-            if (!stop) {
-                rb = rng_draw(P.seed, pixel_index, k, (uint32_t)depth, RNG_BOUNCE, 0);
-                stop = rng_uniform(rb.x) > P.p_rr;
-            }
-            if (stop) {
-                h_r[depth] = Ldir.x; h_g[depth] = Ldir.y; h_b[depth] = Ldir.z; h_cos[depth] = 0.0f; h_mat[depth] = mat;
-                break;
-            }
-            F3 ndir = unit3(sample_hemisphere(nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
-            prev.pos = pos; prev.n = nrm; prev.from_dir = ray.d; prev.Ldir = Ldir; prev.mat = mat;
-            ray = make_ray(pos, ndir);
+    float* tstack = reinterpret_cast<float*>(s_lds + 256 * T.stack_cap) + tid;
+    const Pool& pl = T.pool;
+    const uint32_t slot = blockIdx.x * 256u + tid;
+    TravCounters cnt;
+    cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
+    if (slot < pl.n) {
+        float4 rd = pl.rd[slot];
+        uint32_t kind = __float_as_uint(rd.w);
+        if (kind != RAY_NONE) {
+            float4 ro = pl.ro[slot];
+            RayT r;
+            r.o = f3(ro.x, ro.y, ro.z);
+            r.d = f3(rd.x, rd.y, rd.z);
+            r.inv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z); // Ray.cuh:14
+            // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
+            Hit h = trace_ray<MODE, STATS>(T.sc, r, MODE == 0 && kind == RAY_SHADOW, ro.w, stack, tstack, 256, cnt);
+            pl.res[slot] = make_float2(h.t, __int_as_float(h.tri));
         }
-
-        // ---- backward recursion, deepest vertex first: Render.cuh:238-326 ----
-        if (deepest >= 0) {
-            int v = deepest;
-            if (deepest_emissive) {
-                L = v == 0 ? add3(f3(0.0f, 0.0f, 0.0f), deepest_ke) : f3(0.0f, 0.0f, 0.0f); // :249-255, :323
-            } else {
-                L = add3(f3(0.0f, 0.0f, 0.0f), f3(h_r[v], h_g[v], h_b[v])); // final hit: direct light only (:316-319)
-            }
-            for (v = deepest - 1; v >= 0; v--) {
-                float4 fm = sc.mats[h_mat[v] * 3 + 0];
-                F3 ind = mul3(L, f3(fm.x, fm.y, fm.z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
-                ind = scale3(ind, h_cos[v]);
-                ind = scale3(ind, inv_pdf_sphere);
-                ind = div3(ind, P.p_rr);
-                L = add3(ind, f3(h_r[v], h_g[v], h_b[v])); // :323
-            }
-        }
-        P.L[item] = L.x;
-        P.L[P.plane + item] = L.y;
-        P.L[2 * P.plane + item] = L.z;
-    }
-
-    // ---- counters: one atomic per wave ----
-    uint32_t r = wave_sum(cnt.rays), s = wave_sum(cnt.shadow), p = wave_sum(cnt.probe), lv = wave_sum(live ? 1u : 0u);
-    if ((tid & 63) == 0) {
-        atomicAdd(&P.counters[C_RAYS], (unsigned long long)r);
-        atomicAdd(&P.counters[C_SHADOW], (unsigned long long)s);
-        atomicAdd(&P.counters[C_PROBE], (unsigned long long)p);
-        atomicAdd(&P.counters[C_PATHS], (unsigned long long)lv);
     }
     if (STATS) {
         uint32_t a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tests), d = wave_sum(cnt.hits);
-        if ((tid & 63) == 0) {
-            atomicAdd(&P.counters[C_INNER], (unsigned long long)a);
-            atomicAdd(&P.counters[C_LEAF], (unsigned long long)b);
-            atomicAdd(&P.counters[C_TESTS], (unsigned long long)c);
-            atomicAdd(&P.counters[C_HITS], (unsigned long long)d);
+        if ((tid & 63) == 0 && (a | b)) {
+            unsigned long long* cs = T.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+            atomicAdd(&cs[C_INNER], (unsigned long long)a);
+            atomicAdd(&cs[C_LEAF], (unsigned long long)b);
+            atomicAdd(&cs[C_TESTS], (unsigned long long)c);
+            atomicAdd(&cs[C_HITS], (unsigned long long)d);
         }
     }
 }
@@ -483,8 +521,7 @@ struct AParams {
     uint32_t nslots;
     uint32_t chunk_samples;
     uint32_t first_chunk, last_chunk, tiled_output;
-    const float* L;
-    uint64_t plane;
+    const float4* L;
     float* accum;      // 3 planes of nslots (running sum across chunks)
     uint8_t* out_rgb;
     float* out_mean;   // may be null
@@ -508,24 +545,17 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
 {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= A.nslots) return;
-    uint32_t tile = (slot >> 6) * A.world + A.rank, pix = slot & 63u;
     uint32_t i = 0, j = 0;
-    bool valid = tile < A.n_tiles;
-    if (valid) {
-        uint32_t ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
-        i = tx * CRT_TILE + (pix & 7u);
-        j = ty * CRT_TILE + (pix >> 3);
-        valid = i < A.width && j < A.height;
-    }
+    bool valid = slot_to_pixel(slot, A.rank, A.world, A.n_tiles, A.tiles_x, A.width, A.height, i, j);
     F3 c = f3(0.0f, 0.0f, 0.0f);
     if (valid) {
         if (!A.first_chunk) c = f3(A.accum[slot], A.accum[A.nslots + slot], A.accum[2ull * A.nslots + slot]);
         const float fspp = (float)A.spp;
         for (uint32_t s = 0; s < A.chunk_samples; s++) { // temp_color += L / spp, in sample order (Render.cuh:348)
-            uint64_t it = (uint64_t)s * A.nslots + slot;
-            c.x = c.x + A.L[it] / fspp;
-            c.y = c.y + A.L[A.plane + it] / fspp;
-            c.z = c.z + A.L[2 * A.plane + it] / fspp;
+            float4 l = A.L[(uint64_t)s * A.nslots + slot];
+            c.x = c.x + l.x / fspp;
+            c.y = c.y + l.y / fspp;
+            c.z = c.z + l.z / fspp;
         }
         if (!A.last_chunk) {
             A.accum[slot] = c.x; A.accum[A.nslots + slot] = c.y; A.accum[2ull * A.nslots + slot] = c.z;
@@ -552,8 +582,9 @@ __global__ __launch_bounds__(256) void k_intersect(DevScene sc, uint32_t n, cons
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     RayT r = make_ray(f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
-    Counters cnt;
-    Hit h = trace<MODE, false, false>(sc, r, 0.0f, stack, tstack, 256, cnt);
+    TravCounters cnt;
+    cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
+    Hit h = trace_ray<MODE, false>(sc, r, false, 0.0f, stack, tstack, 256, cnt);
     out_tri[i] = h.tri;
     out_t[i] = h.t;
 }
@@ -610,6 +641,10 @@ template <typename T> struct DevBuf {
         HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
         n = count;
     }
+    void ensure(size_t count)
+    {
+        if (n < count) alloc(count);
+    }
     void upload(const std::vector<T>& v)
     {
         alloc(v.size());
@@ -622,6 +657,8 @@ template <typename T> struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+const int kMaxBatch = 64;
+
 } // namespace
 
 struct crt_scene {
@@ -629,12 +666,22 @@ struct crt_scene {
     DevBuf<float4> nodes, tri_geo, mats, ltri;
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint2> lights;
-    DevBuf<float> L, accum;
-    DevBuf<unsigned long long> counters;
+    // path pool + per-item radiance + cross-chunk accumulator
+    DevBuf<float4> p_ro, p_rd, p_vx, p_la, p_cc, p_rec_a, p_rec_b, L;
+    DevBuf<float2> p_res;
+    DevBuf<float> accum;
+    DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
+    DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
+    unsigned long long* h_counters = nullptr; // pinned copy of counters
     DevScene dev{};
     int stack_cap = 0;
     uint32_t n_tris = 0;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev;
+    ~crt_scene()
+    {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (h_counters) (void)hipHostFree(h_counters);
+    }
 };
 
 namespace {
@@ -728,112 +775,173 @@ int validate_desc(const crt_scene_desc* d)
 struct Shard {
     uint32_t tiles_x, tiles_y, n_tiles, local_tiles, nslots;
 };
-Shard make_shard(uint32_t w, uint32_t h, uint32_t rank, uint32_t world)
+Shard make_shard(uint32_t w, uint32_t h, uint32_t world)
 {
     Shard s;
     s.tiles_x = (w + CRT_TILE - 1) / CRT_TILE;
     s.tiles_y = (h + CRT_TILE - 1) / CRT_TILE;
     s.n_tiles = s.tiles_x * s.tiles_y;
     s.local_tiles = (s.n_tiles + world - 1) / world; // padded so every rank writes the same number of slots
-    (void)rank;
     s.nslots = s.local_tiles * 64u;
     return s;
 }
 
-template <int MODE, bool STATS> void launch_paths(const KParams& P, size_t lds, hipStream_t st)
+uint32_t env_u32(const char* name, uint32_t dflt)
 {
-    uint64_t blocks = (P.n_items + 255) / 256;
-    hipLaunchKernelGGL((k_paths<MODE, STATS>), dim3((unsigned)blocks), dim3(256), lds, st, P);
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    long x = std::strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
 }
 
-const uint64_t kMaxChunkItems = 1ull << 28; // 268 M paths per launch -> 3.2 GB of per-path radiance
+const uint64_t kMaxChunkItems = 1ull << 28; // paths per chunk (4.3 GB of per-path radiance)
 
-int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats,
-                bool sync_for_stats)
+template <int MODE, bool STATS> void launch_trace(const TParams& T, uint32_t n, size_t lds, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_trace<MODE, STATS>), dim3((n + 255) / 256), dim3(256), lds, st, T);
+}
+
+int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats)
 {
     if (!sc || !cam || !prm || !d_rgb) return fail(CRT_ERR_INVALID_ARG, "crt_render: null argument");
     if (prm->width == 0 || prm->height == 0 || prm->spp == 0) return fail(CRT_ERR_INVALID_ARG, "crt_render: width, height and spp must be positive");
     if (prm->world == 0 || prm->rank >= prm->world) return fail(CRT_ERR_INVALID_ARG, "crt_render: need rank < world");
-    if (prm->light_sample_n < 0) return fail(CRT_ERR_INVALID_ARG, "crt_render: light_sample_n must be >= 0");
+    if (prm->light_sample_n < 0 || prm->light_sample_n > 4096) return fail(CRT_ERR_INVALID_ARG, "crt_render: light_sample_n must be in [0, 4096]");
     if ((uint64_t)prm->width * prm->height > 0xffffffffull) return fail(CRT_ERR_UNSUPPORTED, "crt_render: more than 2^32 pixels");
     if (prm->traversal != CRT_TRAVERSAL_FAST && prm->traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_render: unknown traversal mode");
     const bool want_stats = (prm->flags & CRT_FLAG_STATS) != 0;
     if (want_stats && prm->traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_render: CRT_FLAG_STATS needs CRT_TRAVERSAL_REFERENCE");
     const bool tiled = (prm->flags & CRT_FLAG_TILED_OUTPUT) != 0;
     if (prm->world > 1 && !tiled) return fail(CRT_ERR_INVALID_ARG, "crt_render: world > 1 needs CRT_FLAG_TILED_OUTPUT");
+    if ((uint64_t)sc->dev.n_lights * (uint64_t)prm->light_sample_n > 0xffffu) return fail(CRT_ERR_UNSUPPORTED, "crt_render: more than 65535 next-event samples per vertex");
     try {
         HIP_CHECK(hipSetDevice(sc->device));
-        Shard sh = make_shard(prm->width, prm->height, prm->rank, prm->world);
+        Shard sh = make_shard(prm->width, prm->height, prm->world);
         uint32_t chunk = (uint32_t)std::min<uint64_t>(prm->spp, std::max<uint64_t>(1, kMaxChunkItems / sh.nslots));
         uint64_t cap = (uint64_t)chunk * sh.nslots;
-        if (sc->L.n < cap * 3) sc->L.alloc(cap * 3);
-        if (sc->accum.n < (size_t)sh.nslots * 3) sc->accum.alloc((size_t)sh.nslots * 3);
-        HIP_CHECK(hipMemsetAsync(sc->counters.p, 0, C_COUNT * sizeof(unsigned long long), st));
+        const uint32_t pool_log2 = std::min(26u, std::max(8u, env_u32("CRT_POOL_LOG2", 22)));
+        const uint32_t pool_n = (uint32_t)std::min<uint64_t>((cap + 255) / 256 * 256, 1ull << pool_log2);
+        const int batch = (int)std::min<uint32_t>(kMaxBatch, env_u32("CRT_ROUND_BATCH", 16));
 
-        KParams P;
+        sc->L.ensure(cap);
+        sc->accum.ensure((size_t)sh.nslots * 3);
+        sc->p_ro.ensure(pool_n); sc->p_rd.ensure(pool_n); sc->p_vx.ensure(pool_n); sc->p_la.ensure(pool_n);
+        sc->p_cc.ensure(pool_n); sc->p_res.ensure(pool_n);
+        sc->p_rec_a.ensure((size_t)pool_n * CRT_BOUNCE_STACK_SIZE);
+        sc->p_rec_b.ensure((size_t)pool_n * CRT_BOUNCE_STACK_SIZE);
+        const bool timing = stats != nullptr;
+        if (timing && sc->ev.size() < (size_t)(2 * kMaxBatch + 3)) {
+            while (sc->ev.size() < (size_t)(2 * kMaxBatch + 3)) {
+                hipEvent_t e;
+                HIP_CHECK(hipEventCreate(&e));
+                sc->ev.push_back(e);
+            }
+        }
+        const size_t counters_bytes = (size_t)CNT_SHARDS * CNT_STRIDE * sizeof(unsigned long long);
+        HIP_CHECK(hipMemsetAsync(sc->counters.p, 0, counters_bytes, st));
+        auto counter_sum = [&](int c) {
+            unsigned long long v = 0;
+            for (int s = 0; s < CNT_SHARDS; s++) v += sc->h_counters[s * CNT_STRIDE + c];
+            return v;
+        };
+        unsigned long long alive_seen = 0;
+
+        Pool pool;
+        pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.vx = sc->p_vx.p; pool.la = sc->p_la.p; pool.cc = sc->p_cc.p;
+        pool.res = sc->p_res.p; pool.rec_a = sc->p_rec_a.p; pool.rec_b = sc->p_rec_b.p; pool.n = pool_n;
+
+        LParams P;
         std::memset(&P, 0, sizeof(P));
-        P.sc = sc->dev;
+        P.sc = sc->dev; P.pool = pool;
         std::memcpy(P.eye, cam->eye, sizeof(P.eye));
         std::memcpy(P.inv_view, cam->inv_view, sizeof(P.inv_view));
         P.scale = det_tanf(cam->fov_y / 2);                       // Render.cuh:338
         P.ar = (float)prm->width / (float)prm->height;            // Render.cuh:339
-        P.width = prm->width; P.height = prm->height; P.spp = prm->spp;
+        P.width = prm->width; P.height = prm->height;
         P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
         P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
         P.nslots = sh.nslots;
-        P.L = sc->L.p; P.plane = cap;
+        P.L = sc->L.p;
         P.counters = sc->counters.p;
-        P.stack_cap = sc->stack_cap;
-        size_t lds = (size_t)sc->stack_cap * 256 * 4 * 2;
+        P.item_next = sc->item_next.p;
+
+        TParams T;
+        std::memset(&T, 0, sizeof(T));
+        T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p; T.stack_cap = sc->stack_cap;
+        const size_t lds = (size_t)sc->stack_cap * 256 * 4 * 2;
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
         A.width = prm->width; A.height = prm->height; A.spp = prm->spp;
         A.rank = prm->rank; A.world = prm->world; A.tiles_x = sh.tiles_x; A.n_tiles = sh.n_tiles;
         A.nslots = sh.nslots; A.tiled_output = tiled ? 1 : 0;
-        A.L = sc->L.p; A.plane = cap; A.accum = sc->accum.p;
+        A.L = sc->L.p; A.accum = sc->accum.p;
         A.out_rgb = (uint8_t*)d_rgb; A.out_mean = (float*)d_mean;
 
-        HIP_CHECK(hipEventRecord(sc->ev[0], st));
-        float kernel_ms = 0.0f;
-        uint32_t launches = 0;
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+        double trace_ms = 0.0, logic_ms = 0.0;
+        uint32_t trace_launches = 0;
+        hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+        if (timing) {
+            ev_begin = sc->ev[2 * kMaxBatch + 1];
+            ev_end = sc->ev[2 * kMaxBatch + 2];
+            HIP_CHECK(hipEventRecord(ev_begin, st));
+        }
+        const dim3 pool_grid((pool_n + 255) / 256);
         for (uint32_t s0 = 0; s0 < prm->spp; s0 += chunk) {
             uint32_t ns = std::min(chunk, prm->spp - s0);
             P.sample_begin = s0;
-            P.n_items = (uint64_t)ns * sh.nslots;
-            if (P.n_items / 256 + 1 > 0x7fffffffull) throw HipFail{hipErrorInvalidValue, "grid too large"};
-            // the first chunk's path kernel is bracketed by events 1/2 (reported as kernel_ms);
-            // further chunks are identical launches
-            if (s0 == 0) HIP_CHECK(hipEventRecord(sc->ev[1], st));
-            if (prm->traversal == CRT_TRAVERSAL_REFERENCE) {
-                if (want_stats) launch_paths<1, true>(P, lds, st); else launch_paths<1, false>(P, lds, st);
-            } else {
-                launch_paths<0, false>(P, lds, st);
-            }
+            P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
+            P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
+            HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
+            hipLaunchKernelGGL(k_pool_init, pool_grid, dim3(256), 0, st, pool);
             HIP_CHECK(hipGetLastError());
-            if (s0 == 0) HIP_CHECK(hipEventRecord(sc->ev[2], st));
-            launches++;
+            for (;;) {
+                if (timing) HIP_CHECK(hipEventRecord(sc->ev[0], st));
+                for (int b = 0; b < batch; b++) {
+                    hipLaunchKernelGGL(k_logic, pool_grid, dim3(256), 0, st, P);
+                    if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 1], st));
+                    if (prm->traversal == CRT_TRAVERSAL_REFERENCE) {
+                        if (want_stats) launch_trace<1, true>(T, pool_n, lds, st); else launch_trace<1, false>(T, pool_n, lds, st);
+                    } else {
+                        launch_trace<0, false>(T, pool_n, lds, st);
+                    }
+                    if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 2], st));
+                }
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(sc->h_counters, sc->counters.p, counters_bytes, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                if (timing) {
+                    for (int b = 0; b < batch; b++) {
+                        float a = 0.0f, c = 0.0f;
+                        HIP_CHECK(hipEventElapsedTime(&a, sc->ev[2 * b], sc->ev[2 * b + 1]));
+                        HIP_CHECK(hipEventElapsedTime(&c, sc->ev[2 * b + 1], sc->ev[2 * b + 2]));
+                        logic_ms += a; trace_ms += c;
+                    }
+                }
+                trace_launches += (uint32_t)batch;
+                unsigned long long alive_now = counter_sum(C_ALIVE);
+                if (alive_now == alive_seen) break; // no slot emitted a ray during the whole batch: chunk done
+                alive_seen = alive_now;
+            }
             A.chunk_samples = ns;
             A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
             hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
             HIP_CHECK(hipGetLastError());
         }
-        HIP_CHECK(hipEventRecord(sc->ev[3], st));
-        if (stats && sync_for_stats) {
+        if (stats) {
+            HIP_CHECK(hipEventRecord(ev_end, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            unsigned long long c[C_COUNT];
-            HIP_CHECK(hipMemcpy(c, sc->counters.p, sizeof(c), hipMemcpyDeviceToHost));
             std::memset(stats, 0, sizeof(*stats));
-            stats->paths = c[C_PATHS]; stats->rays = c[C_RAYS]; stats->shadow_rays = c[C_SHADOW]; stats->probe_rays = c[C_PROBE];
-            stats->inner_pops = c[C_INNER]; stats->leaf_pops = c[C_LEAF]; stats->tri_tests = c[C_TESTS]; stats->hits = c[C_HITS];
-            HIP_CHECK(hipEventElapsedTime(&kernel_ms, sc->ev[1], sc->ev[2]));
+            stats->paths = counter_sum(C_PATHS); stats->rays = counter_sum(C_RAYS); stats->shadow_rays = counter_sum(C_SHADOW);
+            stats->probe_rays = counter_sum(C_PROBE);
+            stats->inner_pops = counter_sum(C_INNER); stats->leaf_pops = counter_sum(C_LEAF); stats->tri_tests = counter_sum(C_TESTS);
+            stats->hits = counter_sum(C_HITS);
             float total = 0.0f;
-            HIP_CHECK(hipEventElapsedTime(&total, sc->ev[0], sc->ev[3]));
-            // with several identical chunks, scale the first chunk's kernel time by the work share
-            stats->kernel_ms = launches > 1 ? kernel_ms * ((float)prm->spp / (float)chunk) : kernel_ms;
+            HIP_CHECK(hipEventElapsedTime(&total, ev_begin, ev_end));
+            stats->kernel_ms = (float)trace_ms;
+            stats->logic_ms = (float)logic_ms;
             stats->total_ms = total;
-            stats->kernel_launches = launches;
+            stats->kernel_launches = trace_launches;
         }
         return CRT_OK;
     } catch (const HipFail& f) {
@@ -858,7 +966,7 @@ int crt_device_count(int* count)
 int crt_shard_slots(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint64_t* slots)
 {
     if (!slots || width == 0 || height == 0 || world == 0 || rank >= world) return fail(CRT_ERR_INVALID_ARG, "crt_shard_slots: bad arguments");
-    *slots = make_shard(width, height, rank, world).nslots;
+    *slots = make_shard(width, height, world).nslots;
     return CRT_OK;
 }
 
@@ -910,8 +1018,9 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         for (uint32_t i = 0; i < d->n_lights; i++) lights[i] = make_uint2(d->lights[i].first_tri, d->lights[i].count);
         sc->nodes.upload(nodes); sc->tri_geo.upload(geo); sc->tri_mat.upload(tri_mat); sc->mats.upload(mats);
         sc->ltri.upload(ltri); sc->lights.upload(lights); sc->leaf_count.upload(leaf_count);
-        sc->counters.alloc(C_COUNT);
-        for (int i = 0; i < 4; i++) HIP_CHECK(hipEventCreate(&sc->ev[i]));
+        sc->counters.alloc((size_t)CNT_SHARDS * CNT_STRIDE);
+        sc->item_next.alloc((size_t)ITEM_SHARDS * ITEM_STRIDE);
+        HIP_CHECK(hipHostMalloc((void**)&sc->h_counters, (size_t)CNT_SHARDS * CNT_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
         sc->dev.nodes = sc->nodes.p; sc->dev.tri_geo = sc->tri_geo.p; sc->dev.tri_mat = sc->tri_mat.p; sc->dev.mats = sc->mats.p;
         sc->dev.ltri = sc->ltri.p; sc->dev.lights = sc->lights.p; sc->dev.leaf_count = sc->leaf_count.p;
         sc->dev.root_ref = root_ref; sc->dev.n_lights = (int32_t)d->n_lights;
@@ -934,15 +1043,13 @@ int crt_scene_destroy(crt_scene* sc)
 {
     if (!sc) return CRT_OK;
     (void)hipSetDevice(sc->device);
-    for (int i = 0; i < 4; i++)
-        if (sc->ev[i]) (void)hipEventDestroy(sc->ev[i]);
     delete sc;
     return CRT_OK;
 }
 
 int crt_render_device(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, void* stream, crt_stats* stats)
 {
-    return render_impl(sc, cam, prm, d_rgb, d_mean, (hipStream_t)stream, stats, true);
+    return render_impl(sc, cam, prm, d_rgb, d_mean, (hipStream_t)stream, stats);
 }
 
 int crt_render(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint8_t* out_rgb, float* out_mean, crt_stats* stats)
@@ -952,12 +1059,12 @@ int crt_render(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint
     try {
         HIP_CHECK(hipSetDevice(sc->device));
         const bool tiled = (prm->flags & CRT_FLAG_TILED_OUTPUT) != 0;
-        uint64_t npix = tiled ? make_shard(prm->width, prm->height, prm->rank, prm->world).nslots : (uint64_t)prm->width * prm->height;
+        uint64_t npix = tiled ? make_shard(prm->width, prm->height, prm->world).nslots : (uint64_t)prm->width * prm->height;
         DevBuf<uint8_t> d_rgb;
         DevBuf<float> d_mean;
         d_rgb.alloc(npix * 3);
         if (out_mean) d_mean.alloc(npix * 3);
-        int rc = render_impl(sc, cam, prm, d_rgb.p, out_mean ? d_mean.p : nullptr, nullptr, stats, true);
+        int rc = render_impl(sc, cam, prm, d_rgb.p, out_mean ? d_mean.p : nullptr, nullptr, stats);
         if (rc != CRT_OK) return rc;
         HIP_CHECK(hipDeviceSynchronize()); // Render.cuh:440
         HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, npix * 3, hipMemcpyDeviceToHost)); // Render.cuh:464

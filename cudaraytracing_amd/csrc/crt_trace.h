@@ -1,0 +1,206 @@
+// cudaraytracing_amd/csrc/crt_trace.h -- BVH traversal and samplers (device).
+//
+// Reference semantics (DeviceBVH.cuh:128-170, :31-43, DeviceTriangle.cuh:39-65):
+// every node whose box passes hit_AABB is visited (no pruning; the root box is
+// never tested), right child first; inside a leaf the first triangle among
+// equal t wins (strict <), and an earlier-visited leaf wins equal t.  Leaves are
+// therefore visited in DESCENDING order of their first-triangle index, so the
+// winner among equal-t candidates is "largest leaf start, then smallest
+// triangle index".  Encoding that rule explicitly makes the result independent
+// of visit order, which is what lets the FAST mode (near-first order, pruning of
+// boxes that start beyond the current best by a conservative margin, any-hit
+// exit for shadow rays) return exactly what the exhaustive REFERENCE mode does.
+#ifndef CRT_TRACE_H
+#define CRT_TRACE_H
+
+#include "crt_device.h"
+
+#include <cfloat>
+
+namespace crtdev {
+
+struct TravCounters {
+    uint32_t inner, leaf, tests, hits;
+};
+
+struct Hit {
+    float t;
+    int32_t tri;      // BVH-order triangle index, -1 = miss
+    int32_t leaf_it;  // first triangle of the leaf that produced it
+};
+
+// reference: DeviceBVH.cuh:87-126.  nx/ny/nz = dir component < 0 (the swap).
+__device__ __forceinline__ bool slab_test(float4 lo, float4 hi, const RayT& r, bool nx, bool ny, bool nz, float& t_enter)
+{
+    float tx0 = ((nx ? hi.x : lo.x) - r.o.x) * r.inv.x;
+    float tx1 = ((nx ? lo.x : hi.x) - r.o.x) * r.inv.x;
+    float ty0 = ((ny ? hi.y : lo.y) - r.o.y) * r.inv.y;
+    float ty1 = ((ny ? lo.y : hi.y) - r.o.y) * r.inv.y;
+    float tz0 = ((nz ? hi.z : lo.z) - r.o.z) * r.inv.z;
+    float tz1 = ((nz ? lo.z : hi.z) - r.o.z) * r.inv.z;
+    t_enter = maxf_ref(maxf_ref(tx0, ty0), tz0);
+    float t_exit = minf_ref(minf_ref(tx1, ty1), tz1);
+    return t_enter <= t_exit + CRT_EPSILON && t_exit >= 0;
+}
+
+// Conservative pruning bound: a box may be skipped only if it starts beyond this.
+// The slack absorbs the rounding difference between the slab arithmetic and the
+// Moeller-Trumbore t of a triangle inside the box (validated by running FAST
+// against REFERENCE on full frames, tests/test_gpu_parity.py).
+__device__ __forceinline__ float prune_bound(float t) { return t + (absf(t) * 1.0e-3f + 1.0e-3f); }
+
+// Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 + the t > EPSILON
+// filter of DeviceBVHNode::hit (DeviceBVH.cuh:37).  Returns true for an accepted hit.
+__device__ __forceinline__ bool tri_test(const DevScene& sc, int i, const RayT& r, float& t_out)
+{
+    const float4* g = sc.tri_geo + (size_t)i * 3;
+    float4 A = g[0], B = g[1], C = g[2];
+    F3 v1 = f3(A.x, A.y, A.z), e1 = f3(A.w, B.x, B.y), e2 = f3(B.z, B.w, C.x);
+    F3 s = sub3(r.o, v1);
+    F3 s1 = cross3(r.d, e2);
+    F3 s2 = cross3(s, e1);
+    float reciprocal = 1 / dot3(s1, e1);
+    float beta = dot3(s1, s) * reciprocal;
+    float gamma = dot3(s2, r.d) * reciprocal;
+    float t = dot3(s2, e2) * reciprocal;
+    float alpha = 1 - beta - gamma;
+    bool inside = 0 < alpha && alpha < 1 && 0 < beta && beta < 1 && 0 < gamma && gamma < 1;
+    t_out = t;
+    return inside && t > CRT_EPSILON;
+}
+
+// MODE 0 = FAST, 1 = REFERENCE.  any_hit (FAST only): shadow query "exists an accepted hit
+// with t_limit - t > EPSILON"; that is equivalent to the reference's closest-hit test in
+// blocked() (Render.cuh:19-27) because float subtraction is monotone in t.  The returned
+// hit.t is then the t of the blocking triangle, FLT_MAX if there is none.
+template <int MODE, bool STATS>
+__device__ __forceinline__ Hit trace_ray(const DevScene& sc, const RayT& r, bool any_hit, float t_limit, int* stack, float* tstack,
+                                         int lane_stride, TravCounters& cnt)
+{
+    Hit best;
+    best.t = FLT_MAX; best.tri = -1; best.leaf_it = -1;
+    const bool nx = r.d.x < 0, ny = r.d.y < 0, nz = r.d.z < 0;
+    int sp = 0;
+    int ref = sc.root_ref;
+    bool have = true;
+    float bound = FLT_MAX;
+    if (MODE == 0 && any_hit) {
+        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit (bound = +inf)
+        if (!(t_limit == t_limit) || t_limit == -pinf()) return best;
+        bound = prune_bound(t_limit);
+    }
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            sp--;
+            ref = stack[sp * lane_stride];
+            if (MODE == 0) {
+                float ref_t = tstack[sp * lane_stride];
+                if (ref_t > bound) continue; // pruned after a closer hit was found
+            }
+        }
+        have = false;
+        if (ref >= 0) {
+            if (STATS) cnt.inner++;
+            const float4* n = sc.nodes + (size_t)ref * 4;
+            float4 a = n[0], b = n[1], c = n[2], d = n[3];
+            float tl, tr;
+            bool hl = slab_test(a, b, r, nx, ny, nz, tl);
+            bool hr = slab_test(c, d, r, nx, ny, nz, tr);
+            int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
+            if (MODE == 1) {
+                // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
+                if (hl && hr) { stack[sp * lane_stride] = lref; sp++; ref = rref; have = true; }
+                else if (hl) { ref = lref; have = true; }
+                else if (hr) { ref = rref; have = true; }
+            } else {
+                hl = hl && !(tl > bound);
+                hr = hr && !(tr > bound);
+                if (hl && hr) {
+                    bool left_first = tl <= tr;
+                    stack[sp * lane_stride] = left_first ? rref : lref;
+                    tstack[sp * lane_stride] = left_first ? tr : tl;
+                    sp++;
+                    ref = left_first ? lref : rref;
+                    have = true;
+                } else if (hl) { ref = lref; have = true; }
+                else if (hr) { ref = rref; have = true; }
+            }
+        } else {
+            if (STATS) cnt.leaf++;
+            uint32_t code = (uint32_t)~ref;
+            int it = (int)(code >> 4);
+            int n = (int)(code & 15u);
+            if (n == 0) n = sc.leaf_count[it];
+            for (int i = it; i < it + n; i++) {
+                if (STATS) cnt.tests++;
+                float t;
+                if (tri_test(sc, i, r, t)) {
+                    if (MODE == 0 && any_hit) {
+                        if (t_limit - t > CRT_EPSILON) { best.t = t; best.tri = i; best.leaf_it = it; return best; }
+                    } else if (t < best.t || (t == best.t && it > best.leaf_it)) {
+                        best.t = t; best.tri = i; best.leaf_it = it;
+                        if (MODE == 0) bound = prune_bound(t);
+                    }
+                }
+            }
+        }
+    }
+    if (STATS && best.tri >= 0) cnt.hits++;
+    return best;
+}
+
+// ------------------------------------------------------------- samplers ----
+// reference: include/Global.h:35-50
+__device__ __forceinline__ F3 to_world(F3 a, F3 N)
+{
+    F3 C;
+    if (absf(N.x) > absf(N.y)) {
+        float invLen = 1.0f / sqrt_f(N.x * N.x + N.z * N.z);
+        C = f3(N.z * invLen, 0.0f, -N.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrt_f(N.y * N.y + N.z * N.z);
+        C = f3(0.0f, N.z * invLen, -N.y * invLen);
+    }
+    F3 B = cross3(C, N);
+    return add3(add3(scalel3(a.x, B), scalel3(a.y, C)), scalel3(a.z, N));
+}
+// reference: include/Global.h:57-66
+__device__ __forceinline__ F3 sample_hemisphere(F3 N, float x_1, float x_2)
+{
+    float z = absf(1.0f - 2.0f * x_1);
+    float r = sqrt_f(1.0f - z * z);
+    float phi = (float)(2 * 3.14159265358979323846 * (double)x_2);
+    float sn, cs;
+    det_sincosf(phi, &sn, &cs);
+    return to_world(f3(r * cs, r * sn, z), N);
+}
+// reference: include/Global.h:68-94
+__device__ __forceinline__ F3 sample_lobe(F3 out, float delta_theta, float delta_phi, float u1, float u2)
+{
+    float eta_1 = 2 * u1 - 1;
+    float eta_2 = 2 * u2 - 1;
+    float r = norm3(out);
+    float theta_0 = det_acosf(out.z / r);
+    float phi_0;
+    if ((double)absf(out.x) < 1e-5)
+        phi_0 = out.y > 0.0f ? (float)1.57079632679489661923 : -(float)1.57079632679489661923;
+    else
+        phi_0 = det_atan2f(out.y, out.x);
+    float theta = theta_0 + eta_1 * delta_theta;
+    float phi = phi_0 + eta_2 * delta_phi;
+    float st, ct, sp, cp;
+    det_sincosf(theta, &st, &ct);
+    det_sincosf(phi, &sp, &cp);
+    return f3(st * cp, st * sp, ct);
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+} // namespace crtdev
+#endif

@@ -124,10 +124,10 @@ typedef struct {
     uint64_t rays;               /* closest-hit queries (= DeviceBVH::intersect calls) */
     uint64_t shadow_rays, probe_rays;
     uint64_t inner_pops, leaf_pops, tri_tests, hits; /* reference visit set; CRT_FLAG_STATS + REFERENCE only */
-    float kernel_ms;             /* HIP-event time of the path kernel(s), on their stream */
+    float kernel_ms;             /* sum of the HIP-event times of the traversal kernel (k_trace) launches */
+    float logic_ms;              /* sum of the HIP-event times of the path-logic kernel (k_logic) launches */
     float total_ms;              /* HIP-event time of the whole device pipeline of this call */
-    uint32_t kernel_launches;
-    uint32_t reserved;
+    uint32_t kernel_launches;    /* number of k_trace launches */
 } crt_stats;
 
 /* ------------------------------------------------------------------------
