@@ -96,6 +96,8 @@ struct TParams {
     DevScene sc;
     Pool pool;
     unsigned long long* counters;
+    unsigned int* slot_next;   // [SLOT_SHARDS * SLOT_STRIDE] cursors of the persistent trace kernel
+    uint32_t slots_per_shard;
     int32_t stack_cap;
 };
 
@@ -477,34 +479,204 @@ __global__ __launch_bounds__(256) void k_pool_init(Pool pl)
 }
 
 // ---------------------------------------------------------------- trace ----
+// Persistent traversal kernel.  A wave keeps 64 rays in flight; a lane whose ray is done
+// writes its result and goes idle, and idle lanes are refilled together (one atomic on a
+// sharded cursor per refill) as soon as REFILL_MIN of them are waiting.  Inside, inner-node
+// steps and leaf steps are separate wave-wide phases: a lane that reaches a leaf parks until
+// LEAF_MIN lanes hold one (or nobody has inner work left), so both phases run with most lanes
+// active instead of serialising the two bodies on every iteration.
+#define TR_IDLE 0
+#define TR_INNER 1
+#define TR_LEAF 2
+#define REFILL_MIN 16
+#define LEAF_MIN 24
+#define SLOT_SHARDS 64
+#define SLOT_STRIDE 32
+
+struct TravLane {
+    RayT r;
+    float t_limit, best_t, bound;
+    int32_t best_tri, best_leaf, ref, sp;
+    uint32_t slot;
+    bool any_hit, nx, ny, nz;
+};
+
+// pops the next node that is still within the pruning bound; false = stack empty
+template <int MODE>
+__device__ __forceinline__ bool trav_pop(TravLane& L, const int* stack, const float* tstack)
+{
+    while (L.sp > 0) {
+        L.sp--;
+        L.ref = stack[L.sp * 256];
+        if (MODE == 0 && tstack[L.sp * 256] > L.bound) continue;
+        return true;
+    }
+    return false;
+}
+
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_trace(const TParams T)
 {
     extern __shared__ int s_lds[];
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     int* stack = s_lds + tid;
     float* tstack = reinterpret_cast<float*>(s_lds + 256 * T.stack_cap) + tid;
     const Pool& pl = T.pool;
-    const uint32_t slot = blockIdx.x * 256u + tid;
+    const DevScene& sc = T.sc;
     TravCounters cnt;
     cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
-    if (slot < pl.n) {
-        float4 rd = pl.rd[slot];
-        uint32_t kind = __float_as_uint(rd.w);
-        if (kind != RAY_NONE) {
-            float4 ro = pl.ro[slot];
-            RayT r;
-            r.o = f3(ro.x, ro.y, ro.z);
-            r.d = f3(rd.x, rd.y, rd.z);
-            r.inv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z); // Ray.cuh:14
-            // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
-            Hit h = trace_ray<MODE, STATS>(T.sc, r, MODE == 0 && kind == RAY_SHADOW, ro.w, stack, tstack, 256, cnt);
-            pl.res[slot] = make_float2(h.t, __int_as_float(h.tri));
+
+    const uint32_t per = T.slots_per_shard;
+    uint32_t shard_off = 0; // shards tried so far by this wave (wave-uniform)
+    const uint32_t home = (blockIdx.x * 4u + (uint32_t)(tid >> 6)) & (SLOT_SHARDS - 1);
+    bool exhausted = false;
+    int state = TR_IDLE;
+    TravLane L;
+    L.slot = 0; L.ref = 0; L.sp = 0; L.best_tri = -1; L.best_leaf = -1; L.best_t = FLT_MAX; L.bound = FLT_MAX; L.t_limit = 0.0f;
+    L.any_hit = false; L.nx = L.ny = L.nz = false;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        const unsigned long long idle = __ballot(state == TR_IDLE);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && (n_idle >= REFILL_MIN)) {
+            uint32_t my = 0xffffffffu;
+            if (state == TR_IDLE) {
+                // all idle lanes are active here; take indices shard by shard
+                while (shard_off < SLOT_SHARDS) {
+                    const uint32_t sh = (home + shard_off) & (SLOT_SHARDS - 1);
+                    const uint32_t lo = sh * per;
+                    const uint32_t hi = min(lo + per, pl.n);
+                    unsigned int* cur = T.slot_next + sh * SLOT_STRIDE;
+                    if (lo >= pl.n || lo + __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi) { shard_off++; continue; }
+                    const unsigned long long m = __ballot(my == 0xffffffffu);
+                    if (m == 0) break;
+                    if (my == 0xffffffffu) {
+                        const int leader = __ffsll((long long)m) - 1;
+                        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        unsigned int base = 0;
+                        if (lane == leader) base = atomicAdd(cur, (unsigned int)__popcll(m));
+                        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                        const unsigned long long idx = (unsigned long long)lo + base + rank;
+                        if (idx < hi) my = (uint32_t)idx;
+                    }
+                    if (__ballot(my == 0xffffffffu) == 0) break; // every idle lane served
+                    shard_off++;                                  // this shard ran dry
+                }
+            }
+            // shard_off is advanced by the idle lanes only; make it wave-uniform
+            {
+                uint32_t so = shard_off;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) so = max(so, (uint32_t)__shfl_xor((int)so, o, 64));
+                shard_off = so;
+            }
+            if (shard_off >= SLOT_SHARDS) exhausted = true;
+            if (state == TR_IDLE && my != 0xffffffffu) {
+                float4 rd = pl.rd[my];
+                uint32_t kind = __float_as_uint(rd.w);
+                if (kind != RAY_NONE) {
+                    float4 ro = pl.ro[my];
+                    L.slot = my;
+                    L.r.o = f3(ro.x, ro.y, ro.z);
+                    L.r.d = f3(rd.x, rd.y, rd.z);
+                    L.r.inv = f3(1 / L.r.d.x, 1 / L.r.d.y, 1 / L.r.d.z); // Ray.cuh:14
+                    L.nx = L.r.d.x < 0; L.ny = L.r.d.y < 0; L.nz = L.r.d.z < 0;
+                    L.t_limit = ro.w;
+                    // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
+                    L.any_hit = MODE == 0 && kind == RAY_SHADOW;
+                    L.best_t = FLT_MAX; L.best_tri = -1; L.best_leaf = -1;
+                    L.bound = FLT_MAX;
+                    L.sp = 0;
+                    L.ref = sc.root_ref;
+                    state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+                    if (L.any_hit) {
+                        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
+                        if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) {
+                            pl.res[my] = make_float2(FLT_MAX, __int_as_float(-1));
+                            state = TR_IDLE;
+                        } else {
+                            L.bound = prune_bound(L.t_limit);
+                        }
+                    }
+                }
+            }
+        }
+        const int n_inner = __popcll(__ballot(state == TR_INNER));
+        const int n_leaf = __popcll(__ballot(state == TR_LEAF));
+        if (n_inner == 0 && n_leaf == 0) {
+            if (exhausted) break;
+            continue; // n_idle == 64 >= REFILL_MIN: the next iteration refills
+        }
+        bool finished = false;
+        if (n_leaf >= LEAF_MIN || n_inner == 0) {
+            // ---- leaf phase ----
+            if (state == TR_LEAF) {
+                if (STATS) cnt.leaf++;
+                uint32_t code = (uint32_t)~L.ref;
+                int it = (int)(code >> 4);
+                int n = (int)(code & 15u);
+                if (n == 0) n = sc.leaf_count[it];
+                bool done = false;
+                for (int i = it; i < it + n; i++) {
+                    if (STATS) cnt.tests++;
+                    float t;
+                    if (tri_test(sc, i, L.r, t)) {
+                        if (L.any_hit) {
+                            if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; break; }
+                        } else if (t < L.best_t || (t == L.best_t && it > L.best_leaf)) {
+                            L.best_t = t; L.best_tri = i; L.best_leaf = it;
+                            if (MODE == 0) L.bound = prune_bound(t);
+                        }
+                    }
+                }
+                if (done || !trav_pop<MODE>(L, stack, tstack)) finished = true;
+                else state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+            }
+        } else {
+            // ---- inner phase ----
+            if (state == TR_INNER) {
+                if (STATS) cnt.inner++;
+                const float4* n = sc.nodes + (size_t)L.ref * 4;
+                float4 a = n[0], b = n[1], c = n[2], d = n[3];
+                float tl, tr;
+                bool hl = slab_test(a, b, L.r, L.nx, L.ny, L.nz, tl);
+                bool hr = slab_test(c, d, L.r, L.nx, L.ny, L.nz, tr);
+                int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
+                bool have = true;
+                if (MODE == 1) {
+                    // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
+                    if (hl && hr) { stack[L.sp * 256] = lref; L.sp++; L.ref = rref; }
+                    else if (hl) L.ref = lref;
+                    else if (hr) L.ref = rref;
+                    else have = false;
+                } else {
+                    hl = hl && !(tl > L.bound);
+                    hr = hr && !(tr > L.bound);
+                    if (hl && hr) {
+                        bool left_first = tl <= tr;
+                        stack[L.sp * 256] = left_first ? rref : lref;
+                        tstack[L.sp * 256] = left_first ? tr : tl;
+                        L.sp++;
+                        L.ref = left_first ? lref : rref;
+                    } else if (hl) L.ref = lref;
+                    else if (hr) L.ref = rref;
+                    else have = false;
+                }
+                if (!have && !trav_pop<MODE>(L, stack, tstack)) finished = true;
+                else state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+            }
+        }
+        if (finished) {
+            if (STATS && L.best_tri >= 0) cnt.hits++;
+            pl.res[L.slot] = make_float2(L.best_t, __int_as_float(L.best_tri));
+            state = TR_IDLE;
         }
     }
     if (STATS) {
         uint32_t a = wave_sum(cnt.inner), b = wave_sum(cnt.leaf), c = wave_sum(cnt.tests), d = wave_sum(cnt.hits);
-        if ((tid & 63) == 0 && (a | b)) {
+        if (lane == 0 && (a | b)) {
             unsigned long long* cs = T.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
             atomicAdd(&cs[C_INNER], (unsigned long long)a);
             atomicAdd(&cs[C_LEAF], (unsigned long long)b);
@@ -672,6 +844,8 @@ struct crt_scene {
     DevBuf<float> accum;
     DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
     DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
+    DevBuf<unsigned int> slot_next;           // [SLOT_SHARDS][SLOT_STRIDE]
+    int n_cus = 0;
     unsigned long long* h_counters = nullptr; // pinned copy of counters
     DevScene dev{};
     int stack_cap = 0;
@@ -796,9 +970,15 @@ uint32_t env_u32(const char* name, uint32_t dflt)
 
 const uint64_t kMaxChunkItems = 1ull << 28; // paths per chunk (4.3 GB of per-path radiance)
 
-template <int MODE, bool STATS> void launch_trace(const TParams& T, uint32_t n, size_t lds, hipStream_t st)
+template <int MODE, bool STATS> void launch_trace(const TParams& T, uint32_t blocks, size_t lds, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_trace<MODE, STATS>), dim3((n + 255) / 256), dim3(256), lds, st, T);
+    hipLaunchKernelGGL((k_trace<MODE, STATS>), dim3(blocks), dim3(256), lds, st, T);
+}
+template <int MODE, bool STATS> int trace_blocks_per_cu(size_t lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<MODE, STATS>, 256, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
 }
 
 int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats)
@@ -868,7 +1048,13 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         TParams T;
         std::memset(&T, 0, sizeof(T));
         T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p; T.stack_cap = sc->stack_cap;
+        T.slot_next = sc->slot_next.p;
+        T.slots_per_shard = ((pool_n + SLOT_SHARDS - 1) / SLOT_SHARDS + 63u) & ~63u;
         const size_t lds = (size_t)sc->stack_cap * 256 * 4 * 2;
+        int per_cu = prm->traversal == CRT_TRAVERSAL_REFERENCE ? (want_stats ? trace_blocks_per_cu<1, true>(lds) : trace_blocks_per_cu<1, false>(lds))
+                                                               : trace_blocks_per_cu<0, false>(lds);
+        per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", 64));
+        const uint32_t trace_blocks = std::min<uint32_t>((pool_n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
@@ -899,11 +1085,12 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 if (timing) HIP_CHECK(hipEventRecord(sc->ev[0], st));
                 for (int b = 0; b < batch; b++) {
                     hipLaunchKernelGGL(k_logic, pool_grid, dim3(256), 0, st, P);
+                    HIP_CHECK(hipMemsetAsync(sc->slot_next.p, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 1], st));
                     if (prm->traversal == CRT_TRAVERSAL_REFERENCE) {
-                        if (want_stats) launch_trace<1, true>(T, pool_n, lds, st); else launch_trace<1, false>(T, pool_n, lds, st);
+                        if (want_stats) launch_trace<1, true>(T, trace_blocks, lds, st); else launch_trace<1, false>(T, trace_blocks, lds, st);
                     } else {
-                        launch_trace<0, false>(T, pool_n, lds, st);
+                        launch_trace<0, false>(T, trace_blocks, lds, st);
                     }
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 2], st));
                 }
@@ -1020,6 +1207,12 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->ltri.upload(ltri); sc->lights.upload(lights); sc->leaf_count.upload(leaf_count);
         sc->counters.alloc((size_t)CNT_SHARDS * CNT_STRIDE);
         sc->item_next.alloc((size_t)ITEM_SHARDS * ITEM_STRIDE);
+        sc->slot_next.alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
+        {
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, device));
+            sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
         HIP_CHECK(hipHostMalloc((void**)&sc->h_counters, (size_t)CNT_SHARDS * CNT_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
         sc->dev.nodes = sc->nodes.p; sc->dev.tri_geo = sc->tri_geo.p; sc->dev.tri_mat = sc->tri_mat.p; sc->dev.mats = sc->mats.p;
         sc->dev.ltri = sc->ltri.p; sc->dev.lights = sc->lights.p; sc->dev.leaf_count = sc->leaf_count.p;
