@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -47,7 +48,7 @@ namespace {
 // Statistics counters are sharded over CNT_SHARDS cache lines (16 x u64 each): thousands of
 // atomics per launch on ONE address serialise at the memory side (~12 ns each) and cost more
 // than the kernel itself.  The host sums the shards.
-enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_COUNT };
+enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_COUNT };
 #define CNT_SHARDS 256
 #define CNT_STRIDE 16
 // The work-item cursor is sharded too: shard s hands out items [s*per, (s+1)*per); a wave
@@ -98,7 +99,10 @@ struct TParams {
     unsigned long long* counters;
     unsigned int* slot_next;   // [SLOT_SHARDS * SLOT_STRIDE] cursors of the persistent trace kernel
     uint32_t slots_per_shard;
-    int32_t stack_cap;
+    int32_t stack_cap;         // traversal stack entries per lane kept in LDS
+    int2* spill;               // [level][grid lanes] overflow of deeper entries (rare), L2 resident
+    uint32_t spill_stride;     // grid lanes
+    int32_t refill_min, leaf_min;
 };
 
 // work item slot -> pixel.  false for padding slots (ragged image edge / tile beyond the image).
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(256) void k_pool_init(Pool pl)
 #define TR_IDLE 0
 #define TR_INNER 1
 #define TR_LEAF 2
+#define TR_POP 3
 #define REFILL_MIN 16
 #define LEAF_MIN 24
 #define SLOT_SHARDS 64
@@ -501,31 +506,52 @@ struct TravLane {
     bool any_hit, nx, ny, nz;
 };
 
-// pops the next node that is still within the pruning bound; false = stack empty
-template <int MODE>
-__device__ __forceinline__ bool trav_pop(TravLane& L, const int* stack, const float* tstack)
+// Traversal stack: entry = (node ref, t_enter).  The first `cap` levels live in LDS
+// ([level][thread] int2, conflict free), deeper ones spill to a per-lane global area.
+struct TravStack {
+    int2* lds;        // + threadIdx.x
+    int2* spill;      // + global lane
+    uint32_t spill_stride;
+    int cap;
+};
+__device__ __forceinline__ void trav_push(const TravStack& S, int sp, int ref, float t)
 {
-    while (L.sp > 0) {
-        L.sp--;
-        L.ref = stack[L.sp * 256];
-        if (MODE == 0 && tstack[L.sp * 256] > L.bound) continue;
-        return true;
-    }
-    return false;
+    int2 e = make_int2(ref, __float_as_int(t));
+    if (sp < S.cap) S.lds[sp * 256] = e;                               // ds_write_b64
+    else S.spill[(size_t)(sp - S.cap) * S.spill_stride] = e;
+}
+// Pops ONE entry.  Returns 0 = stack empty, 1 = popped a node to visit (L.ref), 2 = the popped
+// entry lies beyond the pruning bound (the lane pops again on its next turn, so that a wave
+// never serialises a chain of dependent LDS reads inside one step).
+template <int MODE>
+__device__ __forceinline__ int trav_pop(TravLane& L, const TravStack& S)
+{
+    if (L.sp == 0) return 0;
+    L.sp--;
+    int2 e;
+    if (L.sp < S.cap) e = S.lds[L.sp * 256];                           // ds_read_b64
+    else e = S.spill[(size_t)(L.sp - S.cap) * S.spill_stride];
+    L.ref = e.x;
+    if (MODE == 0 && __int_as_float(e.y) > L.bound) return 2;
+    return 1;
 }
 
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_trace(const TParams T)
 {
-    extern __shared__ int s_lds[];
+    extern __shared__ int2 s_lds2[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    int* stack = s_lds + tid;
-    float* tstack = reinterpret_cast<float*>(s_lds + 256 * T.stack_cap) + tid;
+    TravStack S;
+    S.lds = s_lds2 + tid;
+    S.spill = T.spill + (size_t)blockIdx.x * 256u + tid;
+    S.spill_stride = T.spill_stride;
+    S.cap = T.stack_cap;
     const Pool& pl = T.pool;
     const DevScene& sc = T.sc;
     TravCounters cnt;
     cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
+    uint32_t max_sp = 0, sum_sp = 0, ray_sp = 0;
 
     const uint32_t per = T.slots_per_shard;
     uint32_t shard_off = 0; // shards tried so far by this wave (wave-uniform)
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
         // ---- refill idle lanes ----
         const unsigned long long idle = __ballot(state == TR_IDLE);
         const int n_idle = __popcll(idle);
-        if (!exhausted && (n_idle >= REFILL_MIN)) {
+        if (!exhausted && (n_idle >= T.refill_min)) {
             uint32_t my = 0xffffffffu;
             if (state == TR_IDLE) {
                 // all idle lanes are active here; take indices shard by shard
@@ -603,14 +629,21 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                 }
             }
         }
+        bool finished = false;
+        // ---- pop phase: lanes whose subtree is exhausted take the next pending node ----
+        if (state == TR_POP) {
+            int r = trav_pop<MODE>(L, S);
+            if (r == 0) finished = true;
+            else if (r == 1) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+        }
         const int n_inner = __popcll(__ballot(state == TR_INNER));
         const int n_leaf = __popcll(__ballot(state == TR_LEAF));
-        if (n_inner == 0 && n_leaf == 0) {
+        const int n_pop = __popcll(__ballot(state == TR_POP && !finished));
+        if (n_inner == 0 && n_leaf == 0 && n_pop == 0 && __ballot(finished) == 0) {
             if (exhausted) break;
-            continue; // n_idle == 64 >= REFILL_MIN: the next iteration refills
+            continue; // every lane is idle: the next iteration refills
         }
-        bool finished = false;
-        if (n_leaf >= LEAF_MIN || n_inner == 0) {
+        if (n_leaf > 0 && (n_leaf >= T.leaf_min || n_inner == 0)) {
             // ---- leaf phase ----
             if (state == TR_LEAF) {
                 if (STATS) cnt.leaf++;
@@ -631,10 +664,14 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                         }
                     }
                 }
-                if (done || !trav_pop<MODE>(L, stack, tstack)) finished = true;
-                else state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+                if (done) finished = true;
+                else {
+                    int r = trav_pop<MODE>(L, S);
+                    if (r == 0) finished = true;
+                    else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
+                }
             }
-        } else {
+        } else if (n_inner > 0) {
             // ---- inner phase ----
             if (state == TR_INNER) {
                 if (STATS) cnt.inner++;
@@ -647,7 +684,7 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                 bool have = true;
                 if (MODE == 1) {
                     // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
-                    if (hl && hr) { stack[L.sp * 256] = lref; L.sp++; L.ref = rref; }
+                    if (hl && hr) { trav_push(S, L.sp, lref, 0.0f); L.sp++; L.ref = rref; }
                     else if (hl) L.ref = lref;
                     else if (hr) L.ref = rref;
                     else have = false;
@@ -656,20 +693,29 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                     hr = hr && !(tr > L.bound);
                     if (hl && hr) {
                         bool left_first = tl <= tr;
-                        stack[L.sp * 256] = left_first ? rref : lref;
-                        tstack[L.sp * 256] = left_first ? tr : tl;
+                        trav_push(S, L.sp, left_first ? rref : lref, left_first ? tr : tl);
                         L.sp++;
                         L.ref = left_first ? lref : rref;
                     } else if (hl) L.ref = lref;
                     else if (hr) L.ref = rref;
                     else have = false;
                 }
-                if (!have && !trav_pop<MODE>(L, stack, tstack)) finished = true;
-                else state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+                if (STATS && (uint32_t)L.sp > ray_sp) ray_sp = (uint32_t)L.sp;
+                if (have) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+                else {
+                    int r = trav_pop<MODE>(L, S);
+                    if (r == 0) finished = true;
+                    else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
+                }
             }
         }
         if (finished) {
-            if (STATS && L.best_tri >= 0) cnt.hits++;
+            if (STATS) {
+                if (L.best_tri >= 0) cnt.hits++;
+                if (ray_sp > max_sp) max_sp = ray_sp;
+                sum_sp += ray_sp;
+                ray_sp = 0;
+            }
             pl.res[L.slot] = make_float2(L.best_t, __int_as_float(L.best_tri));
             state = TR_IDLE;
         }
@@ -682,6 +728,15 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
             atomicAdd(&cs[C_LEAF], (unsigned long long)b);
             atomicAdd(&cs[C_TESTS], (unsigned long long)c);
             atomicAdd(&cs[C_HITS], (unsigned long long)d);
+        }
+        uint32_t ss = wave_sum(sum_sp);
+        uint32_t ms = max_sp;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
+        if (lane == 0) {
+            unsigned long long* cs = T.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+            atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
+            atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
         }
     }
 }
@@ -845,6 +900,7 @@ struct crt_scene {
     DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
     DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
     DevBuf<unsigned int> slot_next;           // [SLOT_SHARDS][SLOT_STRIDE]
+    DevBuf<int2> spill;                       // traversal stack overflow
     int n_cus = 0;
     unsigned long long* h_counters = nullptr; // pinned copy of counters
     DevScene dev{};
@@ -990,7 +1046,6 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
     if ((uint64_t)prm->width * prm->height > 0xffffffffull) return fail(CRT_ERR_UNSUPPORTED, "crt_render: more than 2^32 pixels");
     if (prm->traversal != CRT_TRAVERSAL_FAST && prm->traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_render: unknown traversal mode");
     const bool want_stats = (prm->flags & CRT_FLAG_STATS) != 0;
-    if (want_stats && prm->traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_render: CRT_FLAG_STATS needs CRT_TRAVERSAL_REFERENCE");
     const bool tiled = (prm->flags & CRT_FLAG_TILED_OUTPUT) != 0;
     if (prm->world > 1 && !tiled) return fail(CRT_ERR_INVALID_ARG, "crt_render: world > 1 needs CRT_FLAG_TILED_OUTPUT");
     if ((uint64_t)sc->dev.n_lights * (uint64_t)prm->light_sample_n > 0xffffu) return fail(CRT_ERR_UNSUPPORTED, "crt_render: more than 65535 next-event samples per vertex");
@@ -1049,12 +1104,22 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         std::memset(&T, 0, sizeof(T));
         T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p; T.stack_cap = sc->stack_cap;
         T.slot_next = sc->slot_next.p;
+        T.refill_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_REFILL_MIN", REFILL_MIN));
+        T.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", LEAF_MIN));
         T.slots_per_shard = ((pool_n + SLOT_SHARDS - 1) / SLOT_SHARDS + 63u) & ~63u;
-        const size_t lds = (size_t)sc->stack_cap * 256 * 4 * 2;
-        int per_cu = prm->traversal == CRT_TRAVERSAL_REFERENCE ? (want_stats ? trace_blocks_per_cu<1, true>(lds) : trace_blocks_per_cu<1, false>(lds))
-                                                               : trace_blocks_per_cu<0, false>(lds);
+        // LDS holds the first levels of the traversal stack; the rest (rarely touched) spills to HBM/L2
+        const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
+        T.stack_cap = lds_cap;
+        const size_t lds = (size_t)lds_cap * 256 * sizeof(int2);
+        const int mode_id = prm->traversal == CRT_TRAVERSAL_REFERENCE ? (want_stats ? 3 : 2) : (want_stats ? 1 : 0);
+        int per_cu = mode_id == 3 ? trace_blocks_per_cu<1, true>(lds) : mode_id == 2 ? trace_blocks_per_cu<1, false>(lds)
+                   : mode_id == 1 ? trace_blocks_per_cu<0, true>(lds) : trace_blocks_per_cu<0, false>(lds);
         per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", 64));
         const uint32_t trace_blocks = std::min<uint32_t>((pool_n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
+        const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
+        T.spill_stride = trace_blocks * 256u;
+        sc->spill.ensure((size_t)spill_levels * T.spill_stride);
+        T.spill = sc->spill.p;
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
@@ -1087,23 +1152,27 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     hipLaunchKernelGGL(k_logic, pool_grid, dim3(256), 0, st, P);
                     HIP_CHECK(hipMemsetAsync(sc->slot_next.p, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 1], st));
-                    if (prm->traversal == CRT_TRAVERSAL_REFERENCE) {
-                        if (want_stats) launch_trace<1, true>(T, trace_blocks, lds, st); else launch_trace<1, false>(T, trace_blocks, lds, st);
-                    } else {
-                        launch_trace<0, false>(T, trace_blocks, lds, st);
-                    }
+                    if (mode_id == 3) launch_trace<1, true>(T, trace_blocks, lds, st);
+                    else if (mode_id == 2) launch_trace<1, false>(T, trace_blocks, lds, st);
+                    else if (mode_id == 1) launch_trace<0, true>(T, trace_blocks, lds, st);
+                    else launch_trace<0, false>(T, trace_blocks, lds, st);
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 2], st));
                 }
                 HIP_CHECK(hipGetLastError());
                 HIP_CHECK(hipMemcpyAsync(sc->h_counters, sc->counters.p, counters_bytes, hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (timing) {
+                    double bl = 0.0, bt = 0.0;
                     for (int b = 0; b < batch; b++) {
                         float a = 0.0f, c = 0.0f;
                         HIP_CHECK(hipEventElapsedTime(&a, sc->ev[2 * b], sc->ev[2 * b + 1]));
                         HIP_CHECK(hipEventElapsedTime(&c, sc->ev[2 * b + 1], sc->ev[2 * b + 2]));
-                        logic_ms += a; trace_ms += c;
+                        bl += a; bt += c;
                     }
+                    logic_ms += bl; trace_ms += bt;
+                    if (std::getenv("CRT_TRACE_LOG"))
+                        fprintf(stderr, "[crt] rounds %u..%u: rays in batch %llu, logic %.3f ms, trace %.3f ms\n", trace_launches, trace_launches + batch - 1,
+                                (unsigned long long)(counter_sum(C_ALIVE) - alive_seen), bl, bt);
                 }
                 trace_launches += (uint32_t)batch;
                 unsigned long long alive_now = counter_sum(C_ALIVE);
@@ -1123,6 +1192,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             stats->probe_rays = counter_sum(C_PROBE);
             stats->inner_pops = counter_sum(C_INNER); stats->leaf_pops = counter_sum(C_LEAF); stats->tri_tests = counter_sum(C_TESTS);
             stats->hits = counter_sum(C_HITS);
+            stats->stack_sum = counter_sum(C_SUMSP);
+            for (int sh2 = 0; sh2 < CNT_SHARDS; sh2++) stats->stack_max = std::max<uint64_t>(stats->stack_max, sc->h_counters[sh2 * CNT_STRIDE + C_MAXSP]);
             float total = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&total, ev_begin, ev_end));
             stats->kernel_ms = (float)trace_ms;
@@ -1220,7 +1291,6 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->n_tris = d->n_tris;
         // Both traversal modes hold at most one pending sibling per tree level.
         sc->stack_cap = depth + 2;
-        if ((size_t)sc->stack_cap * 256 * 8 > 64 * 1024) { delete sc; return fail(CRT_ERR_UNSUPPORTED, "crt_scene_create: BVH deeper than the LDS traversal stack allows"); }
         *out = sc;
         return CRT_OK;
     } catch (const HipFail& f) {

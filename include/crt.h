@@ -104,7 +104,7 @@ enum {
     CRT_TRAVERSAL_REFERENCE = 1  /* exhaustive traversal in the reference's visit order (DeviceBVH.cuh:128-170) */
 };
 enum {
-    CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (REFERENCE traversal only) */
+    CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (slower counting kernels) */
     CRT_FLAG_TILED_OUTPUT = 2u   /* write this rank's pixels in compact 8x8-tile order instead of row-major */
 };
 
@@ -123,7 +123,9 @@ typedef struct {
     uint64_t paths;              /* W*H*spp of this shard */
     uint64_t rays;               /* closest-hit queries (= DeviceBVH::intersect calls) */
     uint64_t shadow_rays, probe_rays;
-    uint64_t inner_pops, leaf_pops, tri_tests, hits; /* reference visit set; CRT_FLAG_STATS + REFERENCE only */
+    uint64_t inner_pops, leaf_pops, tri_tests, hits; /* visit counters of the traversal that ran; CRT_FLAG_STATS only
+                                                         (with CRT_TRAVERSAL_REFERENCE: the reference's visit set) */
+    uint64_t stack_sum, stack_max;                   /* CRT_FLAG_STATS: sum / max over rays of the traversal stack high-water */
     float kernel_ms;             /* sum of the HIP-event times of the traversal kernel (k_trace) launches */
     float logic_ms;              /* sum of the HIP-event times of the path-logic kernel (k_logic) launches */
     float total_ms;              /* HIP-event time of the whole device pipeline of this call */
