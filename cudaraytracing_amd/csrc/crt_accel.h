@@ -1,0 +1,174 @@
+// cudaraytracing_amd/csrc/crt_accel.h -- host-side build of the traversal tree used by
+// CRT_TRAVERSAL_FAST.
+//
+// Why a second tree is legal.  The reference visits a leaf iff the slab test (hit_AABB,
+// DeviceBVH.cuh:87-126) passes for every ancestor box below the root; the leaf's own box is the
+// last of them.  Every ancestor box is the exact float union of the leaf boxes under it
+// (BVH.h:43-52), and for a ray whose inv_dir components are all finite each term of the slab test
+// is monotone in the box bounds (IEEE subtraction, multiplication by a fixed finite factor, the
+// x>y?x:y max/min without NaNs, t_exit + EPSILON): if a box passes, every box that contains it
+// passes.  Hence
+//        the reference tests the triangles of leaf l  <=>  the slab test passes for l's own box,
+// independently of the tree above the leaves.  Any hierarchy over the reference's LEAVES whose
+// inner boxes are exact unions therefore visits a superset of the right leaves, and testing each
+// leaf child's own (reference) box with the reference formula selects exactly the right ones.
+// Rays with a non-finite inv_dir component (a direction component that is zero or denormal) can
+// produce NaNs in the slab test; they keep using the reference-topology tree, for which the
+// traversal performs the reference's own box tests.
+//
+// The reference's median split (BVH.h:63-81) interleaves the scene's few huge wall triangles with
+// the dense meshes, which inflates the boxes along their root paths (measured: 49 inner nodes
+// per ray on the Cornell stand-in even with ordering and pruning).  This builder is a binned
+// surface-area-heuristic BVH over the reference leaves (leaf = one reference leaf).
+#ifndef CRT_ACCEL_H
+#define CRT_ACCEL_H
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdint>
+#include <vector>
+
+namespace crtaccel {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; a++) { lo[a] = FLT_MAX; hi[a] = -FLT_MAX; } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    double half_area() const
+    {
+        double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {          // one reference leaf
+    Box box;           // its box exactly as the reference stores it (DeviceBVHNode AA/BB)
+    int32_t ref;       // encoded leaf reference (negative)
+};
+
+struct Node {          // inner node: two children with their boxes
+    Box box[2];
+    int32_t child[2];  // >= 0: inner node index (breadth-first numbering), < 0: Prim::ref
+};
+
+// Builds the tree; nodes are returned in breadth-first order (root = 0).  Returns the depth
+// (a tree that is a single leaf has depth 1 and no inner nodes; root_ref tells which).
+inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t& root_ref)
+{
+    nodes.clear();
+    const int n = (int)prims.size();
+    if (n == 1) { root_ref = prims[0].ref; return 1; }
+    const int NB = 32;
+    struct Task { int b, e, node, slot, depth; };
+    // temporary tree in build order, renumbered breadth-first at the end
+    struct Tmp { Box box[2]; int32_t child[2]; int depth; };
+    std::vector<Tmp> tmp;
+    std::vector<Task> todo;
+    tmp.push_back(Tmp());
+    tmp[0].depth = 1;
+    // the root "slot" trick: a virtual parent is not needed; handle the root split directly
+    struct Range { int b, e, tmp_index; };
+    std::vector<Range> stack;
+    stack.push_back(Range{0, n, 0});
+    int max_depth = 1;
+    while (!stack.empty()) {
+        Range r = stack.back();
+        stack.pop_back();
+        const int b = r.b, e = r.e, cnt = e - b;
+        // centroid bounds
+        float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = b; i < e; i++)
+            for (int a = 0; a < 3; a++) {
+                float c = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
+                clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c);
+            }
+        int best_axis = -1, best_split = -1;
+        double best_cost = DBL_MAX;
+        for (int a = 0; a < 3; a++) {
+            float ext = chi[a] - clo[a];
+            if (!(ext > 0.0f)) continue;
+            Box bb[NB];
+            int bc[NB];
+            for (int k = 0; k < NB; k++) { bb[k].reset(); bc[k] = 0; }
+            const float scale = (float)NB / ext;
+            for (int i = b; i < e; i++) {
+                float c = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
+                int k = std::min(NB - 1, std::max(0, (int)((c - clo[a]) * scale)));
+                bb[k].grow(prims[i].box);
+                bc[k]++;
+            }
+            double right_area[NB];
+            int right_cnt[NB];
+            Box acc;
+            acc.reset();
+            int c = 0;
+            for (int k = NB - 1; k >= 1; k--) { acc.grow(bb[k]); c += bc[k]; right_area[k] = acc.half_area(); right_cnt[k] = c; }
+            acc.reset();
+            c = 0;
+            for (int k = 0; k < NB - 1; k++) {
+                acc.grow(bb[k]);
+                c += bc[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
+            }
+        }
+        int mid;
+        if (best_axis < 0) {
+            mid = b + cnt / 2; // all centroids coincide: split by index
+        } else {
+            const int a = best_axis;
+            const float scale = (float)NB / (chi[a] - clo[a]);
+            auto it = std::partition(prims.begin() + b, prims.begin() + e, [&](const Prim& p) {
+                float c = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+                int k = std::min(NB - 1, std::max(0, (int)((c - clo[a]) * scale)));
+                return k <= best_split;
+            });
+            mid = (int)(it - prims.begin());
+            if (mid == b || mid == e) mid = b + cnt / 2;
+        }
+        const int halves[2][2] = {{b, mid}, {mid, e}};
+        for (int s = 0; s < 2; s++) {
+            const int hb = halves[s][0], he = halves[s][1];
+            Box bx;
+            bx.reset();
+            for (int i = hb; i < he; i++) bx.grow(prims[i].box);
+            tmp[r.tmp_index].box[s] = bx;
+            if (he - hb == 1) {
+                tmp[r.tmp_index].child[s] = prims[hb].ref;
+                max_depth = std::max(max_depth, tmp[r.tmp_index].depth + 1);
+            } else {
+                Tmp t;
+                t.depth = tmp[r.tmp_index].depth + 1;
+                max_depth = std::max(max_depth, t.depth + 1);
+                tmp.push_back(t);
+                const int ci = (int)tmp.size() - 1;
+                tmp[r.tmp_index].child[s] = ci;
+                stack.push_back(Range{hb, he, ci});
+            }
+        }
+    }
+    // breadth-first renumbering
+    std::vector<int> order, index(tmp.size(), -1);
+    order.push_back(0);
+    index[0] = 0;
+    for (size_t q = 0; q < order.size(); q++)
+        for (int s = 0; s < 2; s++) {
+            int c = tmp[order[q]].child[s];
+            if (c >= 0) { index[c] = (int)order.size(); order.push_back(c); }
+        }
+    nodes.resize(order.size());
+    for (size_t q = 0; q < order.size(); q++) {
+        const Tmp& t = tmp[order[q]];
+        for (int s = 0; s < 2; s++) {
+            nodes[q].box[s] = t.box[s];
+            nodes[q].child[s] = t.child[s] >= 0 ? index[t.child[s]] : t.child[s];
+        }
+    }
+    root_ref = 0;
+    return max_depth;
+}
+
+} // namespace crtaccel
+#endif

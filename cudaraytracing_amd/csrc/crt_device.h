@@ -2,7 +2,8 @@
 // vector helpers shared by the HIP kernels and the upload code.
 //
 // HBM layout (all read-only during a render, replicated per GPU):
-//   nodes      4 x float4 per INNER node, breadth-first order (root = 0):
+//   nodes      4 x float4 per INNER node; two trees over the same leaves live in this array, the
+//              SAH tree of crt_accel.h (root_fast) and the reference topology (root_exact):
 //                [0] = (left.lo.xyz , bits(left_ref))   [1] = (left.hi.xyz , bits(right_ref))
 //                [2] = (right.lo.xyz, 0)                [3] = (right.hi.xyz, 0)
 //              both child boxes live in the parent: one 64 B fetch per inner-node
@@ -39,7 +40,8 @@ struct DevScene {
     const float4* ltri;
     const uint2* lights;
     const int32_t* leaf_count; // only read for leaves with more than 15 triangles
-    int32_t root_ref;
+    int32_t root_fast;   // root of the SAH tree over the reference leaves (crt_accel.h)
+    int32_t root_exact;  // root of the reference-topology tree
     int32_t n_lights;
 };
 

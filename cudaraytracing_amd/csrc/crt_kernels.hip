@@ -26,6 +26,7 @@
 // records.  Results are bit-identical to the CPU oracle (oracle/crt_oracle.cpp).
 // Build: -ffp-contract=off, correctly rounded fp32 divide/sqrt (build.py).
 #include "../../include/crt.h"
+#include "crt_accel.h"
 #include "crt_device.h"
 #include "crt_trace.h"
 
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(256) void k_pool_init(Pool pl)
 #define TR_INNER 1
 #define TR_LEAF 2
 #define TR_POP 3
-#define REFILL_MIN 16
-#define LEAF_MIN 24
+#define REFILL_MIN 32
+#define LEAF_MIN 16
 #define SLOT_SHARDS 64
 #define SLOT_STRIDE 32
 
@@ -615,7 +616,10 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                     L.best_t = FLT_MAX; L.best_tri = -1; L.best_leaf = -1;
                     L.bound = FLT_MAX;
                     L.sp = 0;
-                    L.ref = sc.root_ref;
+                    // rays with a zero / denormal direction component (inv_dir not finite) can put NaNs into the
+                    // slab test; they walk the reference topology, whose box tests are the reference's own (crt_accel.h)
+                    const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
+                    L.ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
                     state = L.ref >= 0 ? TR_INNER : TR_LEAF;
                     if (L.any_hit) {
                         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
@@ -799,21 +803,16 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
 }
 
 // ------------------------------------------------------------ test kernels --
-template <int MODE>
-__global__ __launch_bounds__(256) void k_intersect(DevScene sc, uint32_t n, const float* o, const float* d, int32_t* out_tri,
-                                                   float* out_t, int stack_cap)
+// crt_intersect: loads n host rays into the first n pool slots (direction normalised as Ray's
+// constructor does, Ray.cuh:12-13) so that the production trace kernel answers them.
+__global__ __launch_bounds__(256) void k_fill_rays(Pool pl, uint32_t n, const float* o, const float* d)
 {
-    extern __shared__ int s_lds[];
-    int* stack = s_lds + threadIdx.x;
-    float* tstack = reinterpret_cast<float*>(s_lds + 256 * stack_cap) + threadIdx.x;
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    RayT r = make_ray(f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
-    TravCounters cnt;
-    cnt.inner = cnt.leaf = cnt.tests = cnt.hits = 0;
-    Hit h = trace_ray<MODE, false>(sc, r, false, 0.0f, stack, tstack, 256, cnt);
-    out_tri[i] = h.tri;
-    out_t[i] = h.t;
+    F3 dir = unit3(f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+    pl.ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
+    pl.rd[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)RAY_CLOSEST));
+    pl.res[i] = make_float2(FLT_MAX, __int_as_float(-1));
 }
 
 __global__ void k_math(int fn, uint32_t n, const float* a, const float* b, float* out)
@@ -928,9 +927,12 @@ int fail_hip(const HipFail& f)
 
 float as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 
-// Converts the reference-layout BVH (post-order, boxes in the nodes themselves) into the
-// device layout of crt_device.h.  Returns the tree depth (root = 1).
-int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector<int32_t>& leaf_count, int32_t& root_ref)
+// Builds the device node array (layout: crt_device.h) holding TWO trees over the same leaves:
+//   [0, A)      the SAH tree of crt_accel.h, used by CRT_TRAVERSAL_FAST for rays with finite inv_dir
+//   [A, A + R)  the reference's own topology (post-order BVH re-laid breadth-first), used by
+//               CRT_TRAVERSAL_REFERENCE and by FAST rays whose inv_dir is not finite.
+// Returns the larger tree depth (root = 1).
+int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector<int32_t>& leaf_count, int32_t& root_fast, int32_t& root_exact)
 {
     auto is_leaf = [&](int32_t i) { return d.nodes[i].lc < 0 && d.nodes[i].rc < 0; };
     auto leaf_ref = [&](int32_t i) -> int32_t {
@@ -941,8 +943,32 @@ int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector
     };
     leaf_count.assign(d.n_tris ? d.n_tris : 1, 0);
     nodes.clear();
-    if (is_leaf(d.root)) { root_ref = leaf_ref(d.root); return 1; }
-    // breadth-first numbering of inner nodes
+    if (is_leaf(d.root)) { root_fast = root_exact = leaf_ref(d.root); return 1; }
+
+    // ---- SAH tree over the reference leaves ----
+    std::vector<crtaccel::Prim> prims;
+    for (uint32_t i = 0; i < d.n_nodes; i++) {
+        if (!is_leaf((int32_t)i)) continue;
+        crtaccel::Prim p;
+        for (int a = 0; a < 3; a++) { p.box.lo[a] = d.nodes[i].aa[a]; p.box.hi[a] = d.nodes[i].bb[a]; }
+        p.ref = leaf_ref((int32_t)i);
+        prims.push_back(p);
+    }
+    std::vector<crtaccel::Node> acc;
+    int32_t acc_root = 0;
+    int depth_fast = crtaccel::build_sah(prims, acc, acc_root);
+    const int32_t A = (int32_t)acc.size();
+    nodes.resize((size_t)A * 4);
+    for (int32_t q = 0; q < A; q++) {
+        const crtaccel::Node& n = acc[q];
+        nodes[q * 4 + 0] = make_float4(n.box[0].lo[0], n.box[0].lo[1], n.box[0].lo[2], as_float(n.child[0]));
+        nodes[q * 4 + 1] = make_float4(n.box[0].hi[0], n.box[0].hi[1], n.box[0].hi[2], as_float(n.child[1]));
+        nodes[q * 4 + 2] = make_float4(n.box[1].lo[0], n.box[1].lo[1], n.box[1].lo[2], 0.0f);
+        nodes[q * 4 + 3] = make_float4(n.box[1].hi[0], n.box[1].hi[1], n.box[1].hi[2], 0.0f);
+    }
+    root_fast = acc_root; // 0 (two or more leaves here)
+
+    // ---- the reference topology, breadth-first numbering of inner nodes ----
     std::vector<int32_t> order, index(d.n_nodes, -1), depth_of;
     order.push_back(d.root);
     depth_of.push_back(1);
@@ -960,20 +986,21 @@ int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector
             }
         }
     }
-    nodes.resize(order.size() * 4);
+    nodes.resize(((size_t)A + order.size()) * 4);
     for (size_t q = 0; q < order.size(); q++) {
         const crt_bvh_node& n = d.nodes[order[q]];
         const crt_bvh_node& l = d.nodes[n.lc];
         const crt_bvh_node& r = d.nodes[n.rc];
-        int32_t lref = is_leaf(n.lc) ? leaf_ref(n.lc) : index[n.lc];
-        int32_t rref = is_leaf(n.rc) ? leaf_ref(n.rc) : index[n.rc];
-        nodes[q * 4 + 0] = make_float4(l.aa[0], l.aa[1], l.aa[2], as_float(lref));
-        nodes[q * 4 + 1] = make_float4(l.bb[0], l.bb[1], l.bb[2], as_float(rref));
-        nodes[q * 4 + 2] = make_float4(r.aa[0], r.aa[1], r.aa[2], 0.0f);
-        nodes[q * 4 + 3] = make_float4(r.bb[0], r.bb[1], r.bb[2], 0.0f);
+        int32_t lref = is_leaf(n.lc) ? leaf_ref(n.lc) : A + index[n.lc];
+        int32_t rref = is_leaf(n.rc) ? leaf_ref(n.rc) : A + index[n.rc];
+        const size_t o = ((size_t)A + q) * 4;
+        nodes[o + 0] = make_float4(l.aa[0], l.aa[1], l.aa[2], as_float(lref));
+        nodes[o + 1] = make_float4(l.bb[0], l.bb[1], l.bb[2], as_float(rref));
+        nodes[o + 2] = make_float4(r.aa[0], r.aa[1], r.aa[2], 0.0f);
+        nodes[o + 3] = make_float4(r.bb[0], r.bb[1], r.bb[2], 0.0f);
     }
-    root_ref = 0;
-    return max_depth;
+    root_exact = A;
+    return std::max(max_depth, depth_fast);
 }
 
 int validate_desc(const crt_scene_desc* d)
@@ -1035,6 +1062,47 @@ template <int MODE, bool STATS> int trace_blocks_per_cu(size_t lds)
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_trace<MODE, STATS>, 256, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
+}
+
+struct TraceSetup {
+    TParams T;
+    size_t lds;
+    int mode_id;
+    uint32_t blocks;
+};
+// Everything a k_trace launch over `pool` needs (grid sized to the device's residency: the kernel is persistent).
+TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, bool want_stats)
+{
+    TraceSetup S;
+    std::memset(&S.T, 0, sizeof(S.T));
+    TParams& T = S.T;
+    T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p;
+    T.slot_next = sc->slot_next.p;
+    T.refill_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_REFILL_MIN", REFILL_MIN));
+    T.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", LEAF_MIN));
+    T.slots_per_shard = ((pool.n + SLOT_SHARDS - 1) / SLOT_SHARDS + 63u) & ~63u;
+    // LDS holds the first levels of the traversal stack; the rest (rarely touched) spills to HBM/L2
+    const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
+    T.stack_cap = lds_cap;
+    S.lds = (size_t)lds_cap * 256 * sizeof(int2);
+    S.mode_id = reference ? (want_stats ? 3 : 2) : (want_stats ? 1 : 0);
+    int per_cu = S.mode_id == 3 ? trace_blocks_per_cu<1, true>(S.lds) : S.mode_id == 2 ? trace_blocks_per_cu<1, false>(S.lds)
+               : S.mode_id == 1 ? trace_blocks_per_cu<0, true>(S.lds) : trace_blocks_per_cu<0, false>(S.lds);
+    per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", 64));
+    S.blocks = std::min<uint32_t>((pool.n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
+    const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
+    T.spill_stride = S.blocks * 256u;
+    sc->spill.ensure((size_t)spill_levels * T.spill_stride);
+    T.spill = sc->spill.p;
+    return S;
+}
+void launch_trace_pass(crt_scene* sc, const TraceSetup& S, hipStream_t st)
+{
+    HIP_CHECK(hipMemsetAsync(sc->slot_next.p, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
+    if (S.mode_id == 3) launch_trace<1, true>(S.T, S.blocks, S.lds, st);
+    else if (S.mode_id == 2) launch_trace<1, false>(S.T, S.blocks, S.lds, st);
+    else if (S.mode_id == 1) launch_trace<0, true>(S.T, S.blocks, S.lds, st);
+    else launch_trace<0, false>(S.T, S.blocks, S.lds, st);
 }
 
 int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats)
@@ -1100,26 +1168,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         P.counters = sc->counters.p;
         P.item_next = sc->item_next.p;
 
-        TParams T;
-        std::memset(&T, 0, sizeof(T));
-        T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p; T.stack_cap = sc->stack_cap;
-        T.slot_next = sc->slot_next.p;
-        T.refill_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_REFILL_MIN", REFILL_MIN));
-        T.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", LEAF_MIN));
-        T.slots_per_shard = ((pool_n + SLOT_SHARDS - 1) / SLOT_SHARDS + 63u) & ~63u;
-        // LDS holds the first levels of the traversal stack; the rest (rarely touched) spills to HBM/L2
-        const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
-        T.stack_cap = lds_cap;
-        const size_t lds = (size_t)lds_cap * 256 * sizeof(int2);
-        const int mode_id = prm->traversal == CRT_TRAVERSAL_REFERENCE ? (want_stats ? 3 : 2) : (want_stats ? 1 : 0);
-        int per_cu = mode_id == 3 ? trace_blocks_per_cu<1, true>(lds) : mode_id == 2 ? trace_blocks_per_cu<1, false>(lds)
-                   : mode_id == 1 ? trace_blocks_per_cu<0, true>(lds) : trace_blocks_per_cu<0, false>(lds);
-        per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", 64));
-        const uint32_t trace_blocks = std::min<uint32_t>((pool_n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
-        const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
-        T.spill_stride = trace_blocks * 256u;
-        sc->spill.ensure((size_t)spill_levels * T.spill_stride);
-        T.spill = sc->spill.p;
+        TraceSetup TS = make_trace_setup(sc, pool, prm->traversal == CRT_TRAVERSAL_REFERENCE, want_stats);
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
@@ -1150,12 +1199,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 if (timing) HIP_CHECK(hipEventRecord(sc->ev[0], st));
                 for (int b = 0; b < batch; b++) {
                     hipLaunchKernelGGL(k_logic, pool_grid, dim3(256), 0, st, P);
-                    HIP_CHECK(hipMemsetAsync(sc->slot_next.p, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 1], st));
-                    if (mode_id == 3) launch_trace<1, true>(T, trace_blocks, lds, st);
-                    else if (mode_id == 2) launch_trace<1, false>(T, trace_blocks, lds, st);
-                    else if (mode_id == 1) launch_trace<0, true>(T, trace_blocks, lds, st);
-                    else launch_trace<0, false>(T, trace_blocks, lds, st);
+                    launch_trace_pass(sc, TS, st);
                     if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 2], st));
                 }
                 HIP_CHECK(hipGetLastError());
@@ -1244,8 +1289,8 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         HIP_CHECK(hipSetDevice(device));
         std::vector<float4> nodes, geo(d->n_tris * 3ull), mats(d->n_materials * 3ull), ltri(d->n_light_tris * 4ull);
         std::vector<int32_t> leaf_count, tri_mat(d->n_tris);
-        int32_t root_ref = 0;
-        int depth = convert_bvh(*d, nodes, leaf_count, root_ref);
+        int32_t root_fast = 0, root_exact = 0;
+        int depth = convert_bvh(*d, nodes, leaf_count, root_fast, root_exact);
         for (uint32_t i = 0; i < d->n_tris; i++) {
             const crt_triangle& t = d->tris[i];
             // e1 = v2 - v1, e2 = v3 - v1 as DeviceTriangle's constructor computes them (DeviceTriangle.cuh:27-28)
@@ -1287,7 +1332,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         HIP_CHECK(hipHostMalloc((void**)&sc->h_counters, (size_t)CNT_SHARDS * CNT_STRIDE * sizeof(unsigned long long), hipHostMallocDefault));
         sc->dev.nodes = sc->nodes.p; sc->dev.tri_geo = sc->tri_geo.p; sc->dev.tri_mat = sc->tri_mat.p; sc->dev.mats = sc->mats.p;
         sc->dev.ltri = sc->ltri.p; sc->dev.lights = sc->lights.p; sc->dev.leaf_count = sc->leaf_count.p;
-        sc->dev.root_ref = root_ref; sc->dev.n_lights = (int32_t)d->n_lights;
+        sc->dev.root_fast = root_fast; sc->dev.root_exact = root_exact; sc->dev.n_lights = (int32_t)d->n_lights;
         sc->n_tris = d->n_tris;
         // Both traversal modes hold at most one pending sibling per tree level.
         sc->stack_cap = depth + 2;
@@ -1341,23 +1386,30 @@ int crt_render(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint
 int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* dirs, uint32_t traversal, int32_t* out_tri, float* out_t)
 {
     if (!sc || !origins || !dirs || !out_tri || !out_t) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: null argument");
+    if (traversal != CRT_TRAVERSAL_FAST && traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: unknown traversal mode");
     if (n == 0) return CRT_OK;
     try {
         HIP_CHECK(hipSetDevice(sc->device));
-        DevBuf<float> o, d, t;
-        DevBuf<int32_t> tri;
-        o.alloc(n * 3ull); d.alloc(n * 3ull); t.alloc(n); tri.alloc(n);
+        DevBuf<float> o, d;
+        o.alloc(n * 3ull); d.alloc(n * 3ull);
         HIP_CHECK(hipMemcpy(o.p, origins, n * 12ull, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.p, dirs, n * 12ull, hipMemcpyHostToDevice));
-        size_t lds = (size_t)sc->stack_cap * 256 * 8;
-        if (traversal == CRT_TRAVERSAL_REFERENCE)
-            hipLaunchKernelGGL(k_intersect<1>, dim3((n + 255) / 256), dim3(256), lds, 0, sc->dev, n, o.p, d.p, tri.p, t.p, sc->stack_cap);
-        else
-            hipLaunchKernelGGL(k_intersect<0>, dim3((n + 255) / 256), dim3(256), lds, 0, sc->dev, n, o.p, d.p, tri.p, t.p, sc->stack_cap);
+        sc->p_ro.ensure(n); sc->p_rd.ensure(n); sc->p_res.ensure(n);
+        Pool pool;
+        std::memset(&pool, 0, sizeof(pool));
+        pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.res = sc->p_res.p; pool.n = n;
+        hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p);
+        HIP_CHECK(hipGetLastError());
+        TraceSetup TS = make_trace_setup(sc, pool, traversal == CRT_TRAVERSAL_REFERENCE, false);
+        launch_trace_pass(sc, TS, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
-        HIP_CHECK(hipMemcpy(out_tri, tri.p, n * 4ull, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(out_t, t.p, n * 4ull, hipMemcpyDeviceToHost));
+        std::vector<float2> res(n);
+        HIP_CHECK(hipMemcpy(res.data(), sc->p_res.p, n * sizeof(float2), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            out_t[i] = res[i].x;
+            std::memcpy(&out_tri[i], &res[i].y, 4);
+        }
         return CRT_OK;
     } catch (const HipFail& f) {
         return fail_hip(f);

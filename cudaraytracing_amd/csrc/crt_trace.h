@@ -69,87 +69,6 @@ __device__ __forceinline__ bool tri_test(const DevScene& sc, int i, const RayT& 
     return inside && t > CRT_EPSILON;
 }
 
-// MODE 0 = FAST, 1 = REFERENCE.  any_hit (FAST only): shadow query "exists an accepted hit
-// with t_limit - t > EPSILON"; that is equivalent to the reference's closest-hit test in
-// blocked() (Render.cuh:19-27) because float subtraction is monotone in t.  The returned
-// hit.t is then the t of the blocking triangle, FLT_MAX if there is none.
-template <int MODE, bool STATS>
-__device__ __forceinline__ Hit trace_ray(const DevScene& sc, const RayT& r, bool any_hit, float t_limit, int* stack, float* tstack,
-                                         int lane_stride, TravCounters& cnt)
-{
-    Hit best;
-    best.t = FLT_MAX; best.tri = -1; best.leaf_it = -1;
-    const bool nx = r.d.x < 0, ny = r.d.y < 0, nz = r.d.z < 0;
-    int sp = 0;
-    int ref = sc.root_ref;
-    bool have = true;
-    float bound = FLT_MAX;
-    if (MODE == 0 && any_hit) {
-        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit (bound = +inf)
-        if (!(t_limit == t_limit) || t_limit == -pinf()) return best;
-        bound = prune_bound(t_limit);
-    }
-    while (true) {
-        if (!have) {
-            if (sp == 0) break;
-            sp--;
-            ref = stack[sp * lane_stride];
-            if (MODE == 0) {
-                float ref_t = tstack[sp * lane_stride];
-                if (ref_t > bound) continue; // pruned after a closer hit was found
-            }
-        }
-        have = false;
-        if (ref >= 0) {
-            if (STATS) cnt.inner++;
-            const float4* n = sc.nodes + (size_t)ref * 4;
-            float4 a = n[0], b = n[1], c = n[2], d = n[3];
-            float tl, tr;
-            bool hl = slab_test(a, b, r, nx, ny, nz, tl);
-            bool hr = slab_test(c, d, r, nx, ny, nz, tr);
-            int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-            if (MODE == 1) {
-                // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
-                if (hl && hr) { stack[sp * lane_stride] = lref; sp++; ref = rref; have = true; }
-                else if (hl) { ref = lref; have = true; }
-                else if (hr) { ref = rref; have = true; }
-            } else {
-                hl = hl && !(tl > bound);
-                hr = hr && !(tr > bound);
-                if (hl && hr) {
-                    bool left_first = tl <= tr;
-                    stack[sp * lane_stride] = left_first ? rref : lref;
-                    tstack[sp * lane_stride] = left_first ? tr : tl;
-                    sp++;
-                    ref = left_first ? lref : rref;
-                    have = true;
-                } else if (hl) { ref = lref; have = true; }
-                else if (hr) { ref = rref; have = true; }
-            }
-        } else {
-            if (STATS) cnt.leaf++;
-            uint32_t code = (uint32_t)~ref;
-            int it = (int)(code >> 4);
-            int n = (int)(code & 15u);
-            if (n == 0) n = sc.leaf_count[it];
-            for (int i = it; i < it + n; i++) {
-                if (STATS) cnt.tests++;
-                float t;
-                if (tri_test(sc, i, r, t)) {
-                    if (MODE == 0 && any_hit) {
-                        if (t_limit - t > CRT_EPSILON) { best.t = t; best.tri = i; best.leaf_it = it; return best; }
-                    } else if (t < best.t || (t == best.t && it > best.leaf_it)) {
-                        best.t = t; best.tri = i; best.leaf_it = it;
-                        if (MODE == 0) bound = prune_bound(t);
-                    }
-                }
-            }
-        }
-    }
-    if (STATS && best.tri >= 0) cnt.hits++;
-    return best;
-}
-
 // ------------------------------------------------------------- samplers ----
 // reference: include/Global.h:35-50
 __device__ __forceinline__ F3 to_world(F3 a, F3 N)

@@ -50,6 +50,16 @@ def random_rays(name, n, seed):
     o[:half] = eye
     tgt = (lo + (hi - lo) * rng.random((half, 3))).astype(np.float32)
     d[:half] = tgt - eye
-    # a few axis-parallel directions (inv_dir = +-inf, DeviceBVH.cuh:97-121 relies on IEEE semantics)
+    # axis-parallel directions and directions with one zero component (inv_dir = +-inf, DeviceBVH.cuh:97-121
+    # relies on IEEE inf/NaN semantics), some starting exactly on a box plane (0 * inf = NaN in the slab test)
     d[half:half + 6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+    k = min(n // 8, 256)
+    z = d[half + 6:half + 6 + k]
+    z[np.arange(k), rng.integers(0, 3, k)] = 0.0
+    z[::3, rng.integers(0, 3)] = 0.0
+    ob = o[half + 6:half + 6 + k]
+    pick = nodes[rng.integers(0, len(nodes), k)]
+    ax = rng.integers(0, 3, k)
+    side = rng.integers(0, 2, k)
+    ob[np.arange(k), ax] = np.where(side == 0, pick["aa"][np.arange(k), ax], pick["bb"][np.arange(k), ax])
     return o, d
