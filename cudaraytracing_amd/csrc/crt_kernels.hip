@@ -68,9 +68,11 @@ struct Pool {
     float4* vx;   // current vertex position.xyz, bits(triangle)
     float4* la;   // next-event accumulator L_dir.xyz of the current vertex, bits(depth | stage << 8 | sample << 16)
     float4* cc;   // contribution of the in-flight shadow ray .xyz, bits(work item)
+    float4* vn;   // normal.xyz and bits(material) of the current vertex (of the PREVIOUS vertex while a bounce ray is in flight)
+    uint4* id;    // pixel index, sample index, work item, unused -- written once per path
     float2* res;  // result of the slot's last ray: t, bits(triangle or -1)
     float4* rec_a; // [depth][n]: L_dir.xyz of that vertex, cos to the next vertex
-    float4* rec_b; // [depth][n]: incoming direction.xyz, bits(triangle)
+    float4* rec_b; // [depth][n]: incoming direction.xyz, bits(material)
     uint32_t n;
 };
 
@@ -89,6 +91,7 @@ struct LParams {
     uint32_t sample_begin;  // first sample index of this chunk
     uint32_t n_items;       // nslots * samples in this chunk
     uint32_t items_per_shard;
+    uint32_t n_mats;
     unsigned int* item_next; // [ITEM_SHARDS * ITEM_STRIDE] cursors, relative to the shard start
     float4* L;              // per work item radiance
     unsigned long long* counters;
@@ -152,9 +155,9 @@ struct PathCounters {
 };
 
 struct Lane {
-    F3 ro, rd, pos, Ld, c;
+    F3 ro, rd, pos, Ld, c, nrm;
     float tl;
-    uint32_t kind, vtri, depth, stage, q, item;
+    uint32_t kind, vtri, mat, depth, stage, q, item;
     uint32_t pixel_index, k;
 };
 
@@ -168,13 +171,24 @@ __device__ __forceinline__ void decode_item(const LParams& P, uint32_t item, uin
     pixel_index = pj * P.width + pi; // Render.cuh:336
 }
 
+#define LOGIC_TABLE_MAX 64 /* materials / lights kept in LDS when they fit */
+
+// Materials and lights are tiny tables read by every lane: LDS copies when they fit.
+template <bool LDS_TABLES> struct Tables {
+    const float4* mats;
+    const uint2* lights;
+};
+template <bool LDS_TABLES>
+__device__ __forceinline__ float4 mat_row(const Tables<LDS_TABLES>& tb, uint32_t mat, int row) { return tb.mats[mat * 3 + row]; }
+
 // Sets up next-event sample q of the current vertex: Render.cuh:262-272 (+ :274-283 evaluated
 // ahead of the visibility test; the value is only added if the shadow ray is not blocked).
-__device__ __forceinline__ void setup_shadow(const LParams& P, Lane& s, F3 nrm, F3 f_r)
+template <bool LDS_TABLES>
+__device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_TABLES>& tb, Lane& s, F3 f_r)
 {
     const DevScene& sc = P.sc;
     uint32_t li = s.q / (uint32_t)P.lsn, sj = s.q - li * (uint32_t)P.lsn;
-    uint2 lg = sc.lights[li];
+    uint2 lg = tb.lights[li];
     U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, li * (uint32_t)P.lsn + sj);
     uint32_t ti = rl.x % lg.y; // DeviceLights.cuh:35
     const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
@@ -192,7 +206,7 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, Lane& s, F3 nrm, 
     s.kind = RAY_SHADOW;
     float tl = norm3(dist);
     float t2 = tl * tl;
-    float cos_theta = dot3(dir, nrm);
+    float cos_theta = dot3(dir, s.nrm);
     float cos_theta_2 = -dot3(dir, f3(l2.y, l2.z, l2.w));
     cos_theta = cos_theta > 0.0f ? cos_theta : 0.0f;
     cos_theta_2 = cos_theta_2 > 0.0f ? cos_theta_2 : 0.0f;
@@ -207,9 +221,9 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, Lane& s, F3 nrm, 
 }
 
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
-__device__ __forceinline__ F3 finish_path(const LParams& P, uint32_t slot, int deepest, bool emissive, F3 ke)
+template <bool LDS_TABLES>
+__device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TABLES>& tb, uint32_t slot, int deepest, bool emissive, F3 ke)
 {
-    const DevScene& sc = P.sc;
     const Pool& pl = P.pool;
     F3 L = f3(0.0f, 0.0f, 0.0f);
     if (deepest < 0) return L;
@@ -222,8 +236,8 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, uint32_t slot, int d
     }
     for (int v = deepest - 1; v >= 0; v--) {
         float4 a = pl.rec_a[(size_t)v * pl.n + slot];
-        int tri = __float_as_int(pl.rec_b[(size_t)v * pl.n + slot].w);
-        float4 fm = sc.mats[sc.tri_mat[tri] * 3 + 0];
+        uint32_t mat = __float_as_uint(pl.rec_b[(size_t)v * pl.n + slot].w);
+        float4 fm = mat_row(tb, mat, 0);
         F3 ind = mul3(L, f3(fm.x, fm.y, fm.z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
         ind = scale3(ind, a.w);
         ind = scale3(ind, inv_pdf_sphere);
@@ -236,48 +250,55 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, uint32_t slot, int d
 // One pass per round, phases in the order every possible chain runs through them
 // (result -> enter vertex -> roulette/bounce -> finish -> regenerate -> next-event setup), so a
 // wave executes each phase at most once however its lanes are distributed over path stages.
+// The kernel is latency bound (a slot's state streams from HBM): every plane is requested up
+// front, the current / previous vertex's normal and material ride along in the pool instead of
+// being re-derived through triangle -> material lookups.
+template <bool LDS_TABLES>
 __global__ __launch_bounds__(256) void k_logic(const LParams P)
 {
     const DevScene& sc = P.sc;
     const Pool& pl = P.pool;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     __shared__ uint32_t s_cnt[5];
+    __shared__ float4 s_mats[LDS_TABLES ? LOGIC_TABLE_MAX * 3 : 1];
+    __shared__ uint2 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
+    Tables<LDS_TABLES> tb;
+    if (LDS_TABLES) {
+        if (threadIdx.x < (uint32_t)P.n_mats * 3u) s_mats[threadIdx.x] = sc.mats[threadIdx.x];
+        if (threadIdx.x < (uint32_t)sc.n_lights) s_lights[threadIdx.x] = sc.lights[threadIdx.x];
+        tb.mats = s_mats; tb.lights = s_lights;
+    } else {
+        tb.mats = sc.mats; tb.lights = sc.lights;
+    }
     if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+
+    // ---- request the whole slot state at once ----
+    const bool in_range = slot < pl.n;
+    const uint32_t sl = in_range ? slot : 0;
+    float4 la = pl.la[sl];
+    float4 cc = pl.cc[sl], vx = pl.vx[sl], ro = pl.ro[sl], rd = pl.rd[sl], vn = pl.vn[sl];
+    uint4 idv = pl.id[sl];
+    float2 rs = pl.res[sl];
     __syncthreads();
+
     PathCounters cnt;
     cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
     bool emitted = false;
-    uint32_t stage = ST_DEAD, depth = 0, q = 0;
-    float4 la = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (slot < pl.n) {
-        la = pl.la[slot];
-        uint32_t st = __float_as_uint(la.w);
-        depth = st & 255u; stage = (st >> 8) & 15u; q = st >> 16;
-    }
+    uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = in_range ? (st >> 8) & 15u : (uint32_t)ST_DEAD;
     if (stage != ST_DEAD) {
         Lane s;
-        s.depth = depth; s.stage = stage; s.q = q;
+        s.depth = st & 255u; s.stage = stage; s.q = st >> 16;
         s.Ld = f3(la.x, la.y, la.z);
         s.kind = RAY_NONE;
-        s.pixel_index = 0; s.k = 0; s.item = ITEM_NONE;
-        s.c = s.pos = s.ro = s.rd = f3(0.0f, 0.0f, 0.0f);
-        s.tl = 0.0f; s.vtri = 0;
-        float res_t = FLT_MAX;
-        int res_tri = -1;
-        if (stage != ST_NEW) {
-            float4 cc = pl.cc[slot];
-            s.c = f3(cc.x, cc.y, cc.z); s.item = __float_as_uint(cc.w);
-            float4 vx = pl.vx[slot];
-            s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
-            float4 ro = pl.ro[slot], rd = pl.rd[slot];
-            s.ro = f3(ro.x, ro.y, ro.z); s.tl = ro.w;
-            s.rd = f3(rd.x, rd.y, rd.z);
-            float2 rs = pl.res[slot];
-            res_t = rs.x;
-            res_tri = __float_as_int(rs.y);
-            bool v; uint32_t pi, pj;
-            decode_item(P, s.item, s.pixel_index, s.k, v, pi, pj);
-        }
+        s.c = f3(cc.x, cc.y, cc.z);
+        s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
+        s.ro = f3(ro.x, ro.y, ro.z); s.tl = ro.w;
+        s.rd = f3(rd.x, rd.y, rd.z);
+        s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
+        s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
+        const float res_t = rs.x;
+        const int res_tri = __float_as_int(rs.y);
         bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
         int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
 
@@ -295,22 +316,19 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                 do_finish = true;
             } else {
                 F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
-                pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __int_as_float(res_tri));
                 do_enter = true;
                 if (s.depth > 0) {
-                    // the previous vertex is not the deepest one: cosine of its indirect term (Render.cuh:291)
+                    // the previous vertex (normal / material still in the vn plane) is not the deepest one:
+                    // cosine of its indirect term (Render.cuh:291)
                     const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
-                    float4 pb = pl.rec_b[pr];
-                    int ptri = __float_as_int(pb.w);
-                    float4 pg = sc.tri_geo[(size_t)ptri * 3 + 2];
-                    F3 pn = f3(pg.y, pg.z, pg.w);
+                    F3 pn = s.nrm;
                     float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
                     cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
                     pl.rec_a[pr].w = cos_prev;
-                    int pmat = sc.tri_mat[ptri];
-                    float4 pm1 = sc.mats[pmat * 3 + 1];
+                    float4 pm1 = mat_row(tb, s.mat, 1);
                     if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
-                        float ns = sc.mats[pmat * 3 + 0].w;
+                        float ns = mat_row(tb, s.mat, 0).w;
+                        float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
                         float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
                         F3 in = unit3(f3(pb.x, pb.y, pb.z));
                         F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
@@ -318,7 +336,9 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                         float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
                         U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
                         F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
-                        s.rd = unit3(refd); // Ray.cuh:13 (origin stays prev.pos)
+                        // the probe leaves from prev.pos (= this ray's origin); keep the bounce direction for rec_b
+                        pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f);
+                        s.rd = unit3(refd); // Ray.cuh:13
                         s.tl = 0.0f; s.kind = RAY_CLOSEST;
                         s.stage = ST_PROBE;
                         cnt.rays++; cnt.probe++;
@@ -329,18 +349,15 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                 s.pos = pos; s.vtri = (uint32_t)res_tri;
             }
         } else if (stage == ST_PROBE) {
-            // the probe ray of vertex depth-1 (Render.cuh:304-313)
+            // the probe ray of vertex depth-1 (Render.cuh:304-313); vn still describes that vertex
             if (res_tri >= 0) {
                 int hmat = sc.tri_mat[res_tri];
-                float4 q1 = sc.mats[hmat * 3 + 1];
+                float4 q1 = mat_row(tb, hmat, 1);
                 if (__float_as_uint(q1.w) & 1u) {
-                    float4 q2 = sc.mats[hmat * 3 + 2];
+                    float4 q2 = mat_row(tb, hmat, 2);
                     const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
-                    int ptri = __float_as_int(pl.rec_b[pr].w);
-                    float4 pg = sc.tri_geo[(size_t)ptri * 3 + 2];
-                    F3 pn = f3(pg.y, pg.z, pg.w);
-                    int pmat = sc.tri_mat[ptri];
-                    float4 pm0 = sc.mats[pmat * 3 + 0], pm1 = sc.mats[pmat * 3 + 1];
+                    F3 pn = s.nrm;
+                    float4 pm0 = mat_row(tb, s.mat, 0), pm1 = mat_row(tb, s.mat, 1);
                     float log_shininess = det_log10f(pm0.w);
                     float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
                     float ip = (float)(2.0f * 3.14159265358979323846) / 8.f;
@@ -355,31 +372,33 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                     pl.rec_a[pr] = a;
                 }
             }
+            // the bounce direction that found the current vertex was parked in rec_b[depth]
+            float4 pb = pl.rec_b[(size_t)s.depth * pl.n + slot];
+            s.rd = f3(pb.x, pb.y, pb.z);
             do_enter = true;
         }
 
-        // ---- phase 2: a new vertex (pos, vtri) at `depth` ----
-        F3 nrm = f3(0.0f, 0.0f, 0.0f), f_r = f3(0.0f, 0.0f, 0.0f);
-        if (do_enter || do_shadow_setup || do_nee_done) {
+        // ---- phase 2: a new vertex (pos, vtri) at `depth`, reached along s.rd ----
+        F3 f_r = f3(0.0f, 0.0f, 0.0f);
+        if (do_enter) {
             float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
-            nrm = f3(g.y, g.z, g.w);
-        }
-        if (do_enter || do_shadow_setup) {
-            int mat = sc.tri_mat[s.vtri];
-            float4 m0 = sc.mats[mat * 3 + 0];
-            f_r = f3(m0.x, m0.y, m0.z);
-            if (do_enter) {
-                float4 m1 = sc.mats[mat * 3 + 1];
-                if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
-                    float4 m2 = sc.mats[mat * 3 + 2];
-                    fin_deepest = (int)s.depth; fin_emissive = true; fin_ke = f3(m2.x, m2.y, m2.z);
-                    do_finish = true;
-                } else {
-                    s.Ld = f3(0.0f, 0.0f, 0.0f);
-                    s.q = 0;
-                    if (sc.n_lights * P.lsn > 0) do_shadow_setup = true; else do_nee_done = true;
-                }
+            s.nrm = f3(g.y, g.z, g.w);
+            s.mat = (uint32_t)sc.tri_mat[s.vtri];
+            pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
+            float4 m1 = mat_row(tb, s.mat, 1);
+            if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+                float4 m2 = mat_row(tb, s.mat, 2);
+                fin_deepest = (int)s.depth; fin_emissive = true; fin_ke = f3(m2.x, m2.y, m2.z);
+                do_finish = true;
+            } else {
+                s.Ld = f3(0.0f, 0.0f, 0.0f);
+                s.q = 0;
+                if (sc.n_lights * P.lsn > 0) do_shadow_setup = true; else do_nee_done = true;
             }
+        }
+        if (do_shadow_setup) {
+            float4 m0 = mat_row(tb, s.mat, 0);
+            f_r = f3(m0.x, m0.y, m0.z);
         }
 
         // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                 fin_deepest = (int)s.depth; fin_emissive = false;
                 do_finish = true;
             } else {
-                F3 ndir = unit3(sample_hemisphere(nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
+                F3 ndir = unit3(sample_hemisphere(s.nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
                 s.ro = s.pos;
                 s.rd = unit3(ndir); // Ray.cuh:13
                 s.tl = 0.0f; s.kind = RAY_CLOSEST;
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
 
         // ---- phase 4: path complete ----
         if (do_finish) {
-            F3 L = finish_path(P, slot, fin_deepest, fin_emissive, fin_ke);
+            F3 L = finish_path(P, tb, slot, fin_deepest, fin_emissive, fin_ke);
             P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
             do_new = true; // regenerate in place
         }
@@ -424,6 +443,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
                 decode_item(P, s.item, s.pixel_index, s.k, valid, pi, pj);
                 if (!valid) continue; // padding slot of a ragged tile: take another item
                 cnt.paths++;
+                pl.id[slot] = make_uint4(s.pixel_index, s.k, s.item, 0u);
                 U4 rj = rng_draw(P.seed, s.pixel_index, s.k, 0, RNG_JITTER, 0);
                 float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
                 float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
@@ -443,20 +463,24 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
 
         // ---- phase 6: next-event sample q of the current vertex ----
         if (do_shadow_setup) {
-            setup_shadow(P, s, nrm, f_r);
+            setup_shadow(P, tb, s, f_r);
             s.stage = ST_SHADOW;
             cnt.rays++; cnt.shadow++;
             emitted = true;
         }
 
         // ---- write the slot back ----
-        uint32_t st = s.depth | (s.stage << 8) | (s.q << 16);
+        st = s.depth | (s.stage << 8) | (s.q << 16);
         pl.la[slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(st));
         if (emitted) {
-            pl.cc[slot] = make_float4(s.c.x, s.c.y, s.c.z, __uint_as_float(s.item));
-            pl.vx[slot] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
             pl.ro[slot] = make_float4(s.ro.x, s.ro.y, s.ro.z, s.tl);
             pl.rd[slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.kind));
+            if (s.stage == ST_SHADOW) pl.cc[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+            if (stage != ST_SHADOW) {
+                // the vertex planes only change when a result was a new vertex
+                pl.vx[slot] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
+                pl.vn[slot] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
+            }
         } else {
             pl.rd[slot].w = __uint_as_float((uint32_t)RAY_NONE);
         }
@@ -893,13 +917,17 @@ struct crt_scene {
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint2> lights;
     // path pool + per-item radiance + cross-chunk accumulator
-    DevBuf<float4> p_ro, p_rd, p_vx, p_la, p_cc, p_rec_a, p_rec_b, L;
+    DevBuf<float4> p_ro, p_rd, p_vx, p_la, p_cc, p_vn, p_rec_a, p_rec_b, L;
+    DevBuf<uint4> p_id;
+    uint32_t n_mats = 0;
     DevBuf<float2> p_res;
     DevBuf<float> accum;
     DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
     DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
-    DevBuf<unsigned int> slot_next;           // [SLOT_SHARDS][SLOT_STRIDE]
-    DevBuf<int2> spill;                       // traversal stack overflow
+    DevBuf<unsigned int> slot_next[2];        // [SLOT_SHARDS][SLOT_STRIDE], one per pool half
+    DevBuf<int2> spill[2];                    // traversal stack overflow, one per pool half
+    hipStream_t aux_stream = nullptr;         // second pool half runs here so that k_logic overlaps k_trace
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int n_cus = 0;
     unsigned long long* h_counters = nullptr; // pinned copy of counters
     DevScene dev{};
@@ -909,6 +937,9 @@ struct crt_scene {
     ~crt_scene()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (aux_stream) (void)hipStreamDestroy(aux_stream);
         if (h_counters) (void)hipHostFree(h_counters);
     }
 };
@@ -1071,13 +1102,13 @@ struct TraceSetup {
     uint32_t blocks;
 };
 // Everything a k_trace launch over `pool` needs (grid sized to the device's residency: the kernel is persistent).
-TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, bool want_stats)
+TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, bool want_stats, int half = 0, int n_halves = 1)
 {
     TraceSetup S;
     std::memset(&S.T, 0, sizeof(S.T));
     TParams& T = S.T;
     T.sc = sc->dev; T.pool = pool; T.counters = sc->counters.p;
-    T.slot_next = sc->slot_next.p;
+    T.slot_next = sc->slot_next[half].p;
     T.refill_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_REFILL_MIN", REFILL_MIN));
     T.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", LEAF_MIN));
     T.slots_per_shard = ((pool.n + SLOT_SHARDS - 1) / SLOT_SHARDS + 63u) & ~63u;
@@ -1088,17 +1119,19 @@ TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, boo
     S.mode_id = reference ? (want_stats ? 3 : 2) : (want_stats ? 1 : 0);
     int per_cu = S.mode_id == 3 ? trace_blocks_per_cu<1, true>(S.lds) : S.mode_id == 2 ? trace_blocks_per_cu<1, false>(S.lds)
                : S.mode_id == 1 ? trace_blocks_per_cu<0, true>(S.lds) : trace_blocks_per_cu<0, false>(S.lds);
-    per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", 64));
+    // with two pool halves in flight leave room for the other half's k_logic blocks
+    const uint32_t dflt_per_cu = n_halves > 1 ? (uint32_t)std::max(1, per_cu - 2) : 64u;
+    per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", dflt_per_cu));
     S.blocks = std::min<uint32_t>((pool.n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
     const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
     T.spill_stride = S.blocks * 256u;
-    sc->spill.ensure((size_t)spill_levels * T.spill_stride);
-    T.spill = sc->spill.p;
+    sc->spill[half].ensure((size_t)spill_levels * T.spill_stride);
+    T.spill = sc->spill[half].p;
     return S;
 }
 void launch_trace_pass(crt_scene* sc, const TraceSetup& S, hipStream_t st)
 {
-    HIP_CHECK(hipMemsetAsync(sc->slot_next.p, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
+    HIP_CHECK(hipMemsetAsync(S.T.slot_next, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
     if (S.mode_id == 3) launch_trace<1, true>(S.T, S.blocks, S.lds, st);
     else if (S.mode_id == 2) launch_trace<1, false>(S.T, S.blocks, S.lds, st);
     else if (S.mode_id == 1) launch_trace<0, true>(S.T, S.blocks, S.lds, st);
@@ -1128,13 +1161,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
 
         sc->L.ensure(cap);
         sc->accum.ensure((size_t)sh.nslots * 3);
-        sc->p_ro.ensure(pool_n); sc->p_rd.ensure(pool_n); sc->p_vx.ensure(pool_n); sc->p_la.ensure(pool_n);
-        sc->p_cc.ensure(pool_n); sc->p_res.ensure(pool_n);
-        sc->p_rec_a.ensure((size_t)pool_n * CRT_BOUNCE_STACK_SIZE);
-        sc->p_rec_b.ensure((size_t)pool_n * CRT_BOUNCE_STACK_SIZE);
         const bool timing = stats != nullptr;
-        if (timing && sc->ev.size() < (size_t)(2 * kMaxBatch + 3)) {
-            while (sc->ev.size() < (size_t)(2 * kMaxBatch + 3)) {
+        if (timing && sc->ev.size() < (size_t)(4 * kMaxBatch + 4)) {
+            while (sc->ev.size() < (size_t)(4 * kMaxBatch + 4)) {
                 hipEvent_t e;
                 HIP_CHECK(hipEventCreate(&e));
                 sc->ev.push_back(e);
@@ -1149,13 +1178,29 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        Pool pool;
-        pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.vx = sc->p_vx.p; pool.la = sc->p_la.p; pool.cc = sc->p_cc.p;
-        pool.res = sc->p_res.p; pool.rec_a = sc->p_rec_a.p; pool.rec_b = sc->p_rec_b.p; pool.n = pool_n;
+        // The pool is split into halves that run on two streams: the HBM-bound k_logic of one half
+        // overlaps the issue-bound k_trace of the other.
+        const int n_halves = (pool_n >= 2 * 65536u && env_u32("CRT_STREAMS", 2) >= 2) ? 2 : 1;
+        const uint32_t half_n = n_halves == 2 ? ((pool_n / 2 + 255) / 256 * 256) : pool_n;
+        sc->p_ro.ensure((size_t)half_n * n_halves); sc->p_rd.ensure((size_t)half_n * n_halves); sc->p_vx.ensure((size_t)half_n * n_halves);
+        sc->p_la.ensure((size_t)half_n * n_halves); sc->p_cc.ensure((size_t)half_n * n_halves); sc->p_res.ensure((size_t)half_n * n_halves);
+        sc->p_vn.ensure((size_t)half_n * n_halves); sc->p_id.ensure((size_t)half_n * n_halves);
+        sc->p_rec_a.ensure((size_t)half_n * n_halves * CRT_BOUNCE_STACK_SIZE);
+        sc->p_rec_b.ensure((size_t)half_n * n_halves * CRT_BOUNCE_STACK_SIZE);
+        Pool pools[2];
+        for (int h = 0; h < n_halves; h++) {
+            Pool& pool = pools[h];
+            const size_t o = (size_t)h * half_n;
+            pool.ro = sc->p_ro.p + o; pool.rd = sc->p_rd.p + o; pool.vx = sc->p_vx.p + o; pool.la = sc->p_la.p + o; pool.cc = sc->p_cc.p + o;
+            pool.vn = sc->p_vn.p + o; pool.id = sc->p_id.p + o; pool.res = sc->p_res.p + o;
+            pool.rec_a = sc->p_rec_a.p + o * CRT_BOUNCE_STACK_SIZE; pool.rec_b = sc->p_rec_b.p + o * CRT_BOUNCE_STACK_SIZE;
+            pool.n = half_n;
+        }
+        hipStream_t streams[2] = {st, sc->aux_stream};
 
         LParams P;
         std::memset(&P, 0, sizeof(P));
-        P.sc = sc->dev; P.pool = pool;
+        P.sc = sc->dev;
         std::memcpy(P.eye, cam->eye, sizeof(P.eye));
         std::memcpy(P.inv_view, cam->inv_view, sizeof(P.inv_view));
         P.scale = det_tanf(cam->fov_y / 2);                       // Render.cuh:338
@@ -1167,8 +1212,12 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         P.L = sc->L.p;
         P.counters = sc->counters.p;
         P.item_next = sc->item_next.p;
+        P.n_mats = sc->n_mats;
+        const bool lds_tables = sc->n_mats <= LOGIC_TABLE_MAX && (uint32_t)sc->dev.n_lights <= LOGIC_TABLE_MAX;
 
-        TraceSetup TS = make_trace_setup(sc, pool, prm->traversal == CRT_TRAVERSAL_REFERENCE, want_stats);
+        TraceSetup TS[2];
+        LParams PH[2];
+        for (int h = 0; h < n_halves; h++) TS[h] = make_trace_setup(sc, pools[h], prm->traversal == CRT_TRAVERSAL_REFERENCE, want_stats, h, n_halves);
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
@@ -1182,44 +1231,66 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         uint32_t trace_launches = 0;
         hipEvent_t ev_begin = nullptr, ev_end = nullptr;
         if (timing) {
-            ev_begin = sc->ev[2 * kMaxBatch + 1];
-            ev_end = sc->ev[2 * kMaxBatch + 2];
+            ev_begin = sc->ev[4 * kMaxBatch + 2];
+            ev_end = sc->ev[4 * kMaxBatch + 3];
             HIP_CHECK(hipEventRecord(ev_begin, st));
         }
-        const dim3 pool_grid((pool_n + 255) / 256);
+        const dim3 pool_grid((half_n + 255) / 256);
+        const int evs_per_half = 2 * kMaxBatch + 1;
         for (uint32_t s0 = 0; s0 < prm->spp; s0 += chunk) {
             uint32_t ns = std::min(chunk, prm->spp - s0);
             P.sample_begin = s0;
             P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
             P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
             HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
-            hipLaunchKernelGGL(k_pool_init, pool_grid, dim3(256), 0, st, pool);
+            for (int h = 0; h < n_halves; h++) {
+                PH[h] = P;
+                PH[h].pool = pools[h];
+                hipLaunchKernelGGL(k_pool_init, pool_grid, dim3(256), 0, st, pools[h]);
+            }
             HIP_CHECK(hipGetLastError());
             for (;;) {
-                if (timing) HIP_CHECK(hipEventRecord(sc->ev[0], st));
+                if (n_halves == 2) { // fork: the second half's chain follows what is queued on st so far
+                    HIP_CHECK(hipEventRecord(sc->ev_fork, st));
+                    HIP_CHECK(hipStreamWaitEvent(sc->aux_stream, sc->ev_fork, 0));
+                }
+                for (int h = 0; h < n_halves; h++)
+                    if (timing) HIP_CHECK(hipEventRecord(sc->ev[h * evs_per_half], streams[h]));
                 for (int b = 0; b < batch; b++) {
-                    hipLaunchKernelGGL(k_logic, pool_grid, dim3(256), 0, st, P);
-                    if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 1], st));
-                    launch_trace_pass(sc, TS, st);
-                    if (timing) HIP_CHECK(hipEventRecord(sc->ev[2 * b + 2], st));
+                    for (int h = 0; h < n_halves; h++) {
+                        hipStream_t hs = streams[h];
+                        hipEvent_t* ev = sc->ev.data() + h * evs_per_half;
+                        if (lds_tables) hipLaunchKernelGGL(k_logic<true>, pool_grid, dim3(256), 0, hs, PH[h]);
+                        else hipLaunchKernelGGL(k_logic<false>, pool_grid, dim3(256), 0, hs, PH[h]);
+                        if (timing) HIP_CHECK(hipEventRecord(ev[2 * b + 1], hs));
+                        launch_trace_pass(sc, TS[h], hs);
+                        if (timing) HIP_CHECK(hipEventRecord(ev[2 * b + 2], hs));
+                    }
                 }
                 HIP_CHECK(hipGetLastError());
+                if (n_halves == 2) { // join
+                    HIP_CHECK(hipEventRecord(sc->ev_join, sc->aux_stream));
+                    HIP_CHECK(hipStreamWaitEvent(st, sc->ev_join, 0));
+                }
                 HIP_CHECK(hipMemcpyAsync(sc->h_counters, sc->counters.p, counters_bytes, hipMemcpyDeviceToHost, st));
                 HIP_CHECK(hipStreamSynchronize(st));
                 if (timing) {
                     double bl = 0.0, bt = 0.0;
-                    for (int b = 0; b < batch; b++) {
-                        float a = 0.0f, c = 0.0f;
-                        HIP_CHECK(hipEventElapsedTime(&a, sc->ev[2 * b], sc->ev[2 * b + 1]));
-                        HIP_CHECK(hipEventElapsedTime(&c, sc->ev[2 * b + 1], sc->ev[2 * b + 2]));
-                        bl += a; bt += c;
+                    for (int h = 0; h < n_halves; h++) {
+                        hipEvent_t* ev = sc->ev.data() + h * evs_per_half;
+                        for (int b = 0; b < batch; b++) {
+                            float a = 0.0f, c = 0.0f;
+                            HIP_CHECK(hipEventElapsedTime(&a, ev[2 * b], ev[2 * b + 1]));
+                            HIP_CHECK(hipEventElapsedTime(&c, ev[2 * b + 1], ev[2 * b + 2]));
+                            bl += a; bt += c;
+                        }
                     }
                     logic_ms += bl; trace_ms += bt;
                     if (std::getenv("CRT_TRACE_LOG"))
                         fprintf(stderr, "[crt] rounds %u..%u: rays in batch %llu, logic %.3f ms, trace %.3f ms\n", trace_launches, trace_launches + batch - 1,
                                 (unsigned long long)(counter_sum(C_ALIVE) - alive_seen), bl, bt);
                 }
-                trace_launches += (uint32_t)batch;
+                trace_launches += (uint32_t)(batch * n_halves);
                 unsigned long long alive_now = counter_sum(C_ALIVE);
                 if (alive_now == alive_seen) break; // no slot emitted a ray during the whole batch: chunk done
                 alive_seen = alive_now;
@@ -1323,7 +1394,11 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->ltri.upload(ltri); sc->lights.upload(lights); sc->leaf_count.upload(leaf_count);
         sc->counters.alloc((size_t)CNT_SHARDS * CNT_STRIDE);
         sc->item_next.alloc((size_t)ITEM_SHARDS * ITEM_STRIDE);
-        sc->slot_next.alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
+        sc->slot_next[0].alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
+        sc->slot_next[1].alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
+        HIP_CHECK(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
         {
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -1334,6 +1409,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->dev.ltri = sc->ltri.p; sc->dev.lights = sc->lights.p; sc->dev.leaf_count = sc->leaf_count.p;
         sc->dev.root_fast = root_fast; sc->dev.root_exact = root_exact; sc->dev.n_lights = (int32_t)d->n_lights;
         sc->n_tris = d->n_tris;
+        sc->n_mats = d->n_materials;
         // Both traversal modes hold at most one pending sibling per tree level.
         sc->stack_cap = depth + 2;
         *out = sc;
