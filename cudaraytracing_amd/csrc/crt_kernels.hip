@@ -1120,7 +1120,7 @@ TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, boo
     int per_cu = S.mode_id == 3 ? trace_blocks_per_cu<1, true>(S.lds) : S.mode_id == 2 ? trace_blocks_per_cu<1, false>(S.lds)
                : S.mode_id == 1 ? trace_blocks_per_cu<0, true>(S.lds) : trace_blocks_per_cu<0, false>(S.lds);
     // with two pool halves in flight leave room for the other half's k_logic blocks
-    const uint32_t dflt_per_cu = n_halves > 1 ? (uint32_t)std::max(1, per_cu - 2) : 64u;
+    const uint32_t dflt_per_cu = n_halves > 1 ? 3u : 64u; // measured best on MI355X (C2): 3 trace blocks + logic blocks per CU
     per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_TRACE_BLOCKS_PER_CU", dflt_per_cu));
     S.blocks = std::min<uint32_t>((pool.n + 255) / 256, (uint32_t)(sc->n_cus * per_cu));
     const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
@@ -1157,7 +1157,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         uint64_t cap = (uint64_t)chunk * sh.nslots;
         const uint32_t pool_log2 = std::min(26u, std::max(8u, env_u32("CRT_POOL_LOG2", 22)));
         const uint32_t pool_n = (uint32_t)std::min<uint64_t>((cap + 255) / 256 * 256, 1ull << pool_log2);
-        const int batch = (int)std::min<uint32_t>(kMaxBatch, env_u32("CRT_ROUND_BATCH", 16));
+        const int batch_max = (int)std::min<uint32_t>(kMaxBatch, env_u32("CRT_ROUND_BATCH", 16));
+        int batch = batch_max;
 
         sc->L.ensure(cap);
         sc->accum.ensure((size_t)sh.nslots * 3);
@@ -1293,6 +1294,10 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 trace_launches += (uint32_t)(batch * n_halves);
                 unsigned long long alive_now = counter_sum(C_ALIVE);
                 if (alive_now == alive_seen) break; // no slot emitted a ray during the whole batch: chunk done
+                // once the pool runs dry (no more regeneration) check more often, so that few empty rounds are launched
+                const unsigned long long per_round = (alive_now - alive_seen) / (unsigned long long)batch;
+                batch = per_round * 8 < (unsigned long long)half_n * n_halves ? std::min(batch_max, 4) : batch_max;
+                if (per_round * 512 < (unsigned long long)half_n * n_halves) batch = std::min(batch_max, 2);
                 alive_seen = alive_now;
             }
             A.chunk_samples = ns;
