@@ -1,0 +1,75 @@
+// crt_cli -- headless replacement of the reference's GUI shell for the hot path:
+// reads a config.json (src/main.cu:67-90), ingests the OBJ/MTL files and builds the BVH exactly
+// as render_view() does (src/main.cu:119-145,276), renders one frame with Render::run_view
+// (src/main.cu:371-372) and saves it with Render::save_frame_buffer (src/main.cu:363).
+// The GUI-settable knobs (spp, P_RR, light_sample_n, eye/lookat/up: Gui.h) are flags.
+//
+//   crt_cli <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]
+//           [--eye x y z] [--lookat x y z] [--up x y z] [--reference] [--base-dir DIR] [--device N]
+#include "crt_host.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]\n"
+                             "       [--eye x y z] [--lookat x y z] [--up x y z] [--reference] [--base-dir DIR] [--device N]\n", argv[0]);
+        return 2;
+    }
+    try {
+        crt_task task = crt::load_task(argv[1]);
+        std::string out = "out.png", base_dir = ".";
+        uint64_t seed = 0;
+        int device = 0;
+        bool reference = false;
+        auto need = [&](int i, int n) { if (i + n >= argc) throw crt::Error(CRT_ERR_INVALID_ARG, std::string("missing value after ") + argv[i]); };
+        for (int i = 2; i < argc; i++) {
+            std::string a = argv[i];
+            if (a == "-o") { need(i, 1); out = argv[++i]; }
+            else if (a == "--spp") { need(i, 1); task.spp = (uint32_t)std::atoi(argv[++i]); }
+            else if (a == "--p-rr") { need(i, 1); task.p_rr = (float)std::atof(argv[++i]); }
+            else if (a == "--lsn") { need(i, 1); task.light_sample_n = (uint32_t)std::atoi(argv[++i]); }
+            else if (a == "--seed") { need(i, 1); seed = std::strtoull(argv[++i], nullptr, 10); }
+            else if (a == "--width") { need(i, 1); task.width = (uint32_t)std::atoi(argv[++i]); }
+            else if (a == "--height") { need(i, 1); task.height = (uint32_t)std::atoi(argv[++i]); }
+            else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
+            else if (a == "--base-dir") { need(i, 1); base_dir = argv[++i]; }
+            else if (a == "--reference") reference = true;
+            else if (a == "--eye" || a == "--lookat" || a == "--up") {
+                need(i, 3);
+                float* dst = a == "--eye" ? task.eye_pos : (a == "--lookat" ? task.lookat : task.up);
+                for (int k = 0; k < 3; k++) dst[k] = (float)std::atof(argv[++i]);
+            } else throw crt::Error(CRT_ERR_INVALID_ARG, "unknown option " + a);
+        }
+        crt::Scene scene(task.width, task.height);
+        crt::load_task_scene(task, scene, base_dir);
+        scene.set_BVH(task.bvh_thresh_n);
+        std::printf("triangles: %zu, BVH nodes: %zu, lights: %zu\n", scene.get_triangles().size(), scene.get_bvh().get_nodes_size(),
+                    scene.get_light_objs().size());
+        crt::Render render(&scene, task.spp, task.p_rr, task.light_sample_n, device);
+        render.set_seed(seed);
+        render.set_traversal(reference ? CRT_TRAVERSAL_REFERENCE : CRT_TRAVERSAL_FAST);
+        float inv_view[9];
+        crt::get_inverse_view_matrix(task.eye_pos, task.lookat, task.up, inv_view);
+        float fov_y = task.fov_y * (float)M_PI / 180; // src/main.cu:278
+        auto t0 = std::chrono::high_resolution_clock::now();
+        render.run_view(task.eye_pos, inv_view, fov_y);
+        std::chrono::duration<double> dt = std::chrono::high_resolution_clock::now() - t0;
+        const crt_stats& st = render.last_stats();
+        std::printf("render cost: %.6f seconds (device %.3f ms, %llu rays, %.1f Mrays/s)\n", dt.count(), st.total_ms,
+                    (unsigned long long)st.rays, st.total_ms > 0 ? st.rays / st.total_ms / 1e3 : 0.0);
+        render.save_frame_buffer(out.c_str());
+        std::printf("%s\n", out.c_str());
+        render.free();
+        return 0;
+    } catch (const crt::Error& e) {
+        std::fprintf(stderr, "crt_cli: %s (%s)\n", e.what(), crt_strerror(e.status));
+        return 1;
+    }
+}

@@ -188,3 +188,39 @@ def test_sharded_render_reassembles(renders):
         shards.append(buf)
     img = untile_numpy(np.stack(shards), w, h)
     assert np.array_equal(img, full)
+
+
+def test_cli_renders_config_to_png(tmp_path):
+    """Headless replacement of the reference's GUI shell: config.json -> PNG, identical to the oracle."""
+    import subprocess
+    from PIL import Image
+    from cudaraytracing_amd import build as b
+    cli = b.build_cli()
+    out = str(tmp_path / "veach.png")
+    cfg = util.SCENES["veach-mis"]
+    r = subprocess.run([cli, cfg, "-o", out, "--spp", "2", "--width", "96", "--height", "72", "--seed", "42", "--base-dir", util.ROOT],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "render cost:" in r.stdout
+    t = util.task("veach-mis")
+    eye, iv, fov = util.camera("veach-mis")
+    orgb, _, _, _ = util.oracle_scene("veach-mis").render(eye, iv, fov, 96, 72, 2, t.P_RR, t.light_sample_n, seed=42)
+    assert np.array_equal(np.asarray(Image.open(out)), orgb)
+    bad = subprocess.run([cli, str(tmp_path / "missing.json")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "unable to open config" in bad.stderr
+
+
+def test_errors_are_reported_not_printed(renders):
+    import ctypes as C
+    from cudaraytracing_amd import _capi as capi
+    r = renders["cornell-box"]
+    eye, iv, fov = util.camera("cornell-box")
+    cam = r._cam(eye, iv, fov)
+    buf = np.zeros((8, 8, 3), dtype=np.uint8)
+    prm = r._params(width=8, height=8)
+    prm.spp = 0
+    assert capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), None, None) == -1
+    prm = r._params(rank=1, world=2, width=8, height=8)  # world > 1 needs the tiled layout
+    assert capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), None, None) == -1
+    with pytest.raises(crt.CrtError):
+        crt.Render(util.host_scene("cornell-box"), device=99)

@@ -1,0 +1,151 @@
+"""CPU tests of the product's host layer (C++ loader / BVH / flat export / config / PNG) through the
+C ABI, compared with the oracle's independent restatement, plus the boundary checks that need no GPU."""
+import ctypes as C
+import hashlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cudaraytracing_amd as crt
+from cudaraytracing_amd import _capi as capi
+import oracle_lib as O
+import util
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_flat_scene_matches_oracle_bit_for_bit(name):
+    s, o = util.host_scene(name), util.oracle_scene(name)
+    assert s.nodes().tobytes() == o.nodes().tobytes()
+    assert s.root == o.root
+    t1, t2 = s.triangles(), o.tris()
+    for k in ("v1", "v2", "v3", "normal", "area", "area_of_obj"):
+        assert np.array_equal(util.bits(t1[k]), util.bits(t2[k])), k
+    mats = s.materials()
+    for k in ("kd", "ke", "ns"):
+        assert np.array_equal(util.bits(mats[k][t1["material"]]), util.bits(t2[k])), k
+    assert np.array_equal(mats["mode"][t1["material"]], t2["mode"])
+    assert np.array_equal(mats["has_emit"][t1["material"]], t2["has_emit"])
+    lt = s.light_triangles()
+    cat = np.concatenate([o.light_tris(i) for i in range(o.num_lights)])
+    for k in ("v1", "v2", "v3", "normal", "area_of_obj"):
+        assert np.array_equal(util.bits(lt[k]), util.bits(cat[k])), k
+    lights = s.lights()
+    assert lights["count"].tolist() == [o.light_size(i) for i in range(o.num_lights)]
+    assert lights["first_tri"].tolist() == np.concatenate([[0], np.cumsum(lights["count"])[:-1]]).tolist()
+    assert [(l, a) for l, a, _ in s.objects()] == o.objects()
+
+
+def test_material_table_is_deduplicated():
+    assert len(util.host_scene("veach-mis").materials()) == 9      # 4 plates, 4 lights, floor+wall share one
+    assert len(util.host_scene("cornell-box").materials()) == 6
+
+
+def test_inverse_view_and_fov_match_oracle():
+    rng = np.random.default_rng(2)
+    for name in ("cornell-box", "veach-mis"):
+        t = util.task(name)
+        assert np.array_equal(crt.get_inverse_view_matrix(t.eye_pos, t.lookat, t.up), O.inverse_view(t.eye_pos, t.lookat, t.up))
+    for _ in range(50):
+        e, l, u = rng.normal(size=3) * 100, rng.normal(size=3) * 10, np.array([0.1, 1.0, -0.2])
+        assert np.array_equal(crt.get_inverse_view_matrix(e, l, u), O.inverse_view(e, l, u))
+    # src/main.cu:278: task.fov_y * (float)M_PI / 180 evaluated in float
+    assert crt.fov_to_radians(39.3077) == np.float32(np.float32(np.float32(39.3077) * np.float32(np.pi)) / np.float32(180))
+
+
+def test_task_parses_reference_config_schema(tmp_path):
+    t = util.task("cornell-box")
+    assert (t.width, t.height, t.bvh_thresh_n, t.spp, t.light_sample_n) == (800, 600, 2, 2, 2)
+    assert t.P_RR == np.float32(0.6) and t.fov_y == np.float32(39.3077)
+    assert t.eye_pos.tolist() == [278.0, 273.0, -800.0] and t.lookat.tolist() == [278.0, 273.0, -799.0]
+    v = util.task("veach-mis")
+    assert v.eye_pos[2] == np.float32(1.23612e-06) and v.light_sample_n == 1 and v.spp == 4
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"OBJ_paths": [], "width": 1}')
+    with pytest.raises(crt.CrtError) as e:
+        crt.Task(str(bad))
+    assert e.value.status == -6  # CRT_ERR_PARSE
+    with pytest.raises(crt.CrtError) as e:
+        crt.Task(str(tmp_path / "missing.json"))
+    assert e.value.status == -5  # CRT_ERR_IO
+
+
+def test_loader_error_behaviour(tmp_path):
+    s = crt.Scene(8, 8)
+    with pytest.raises(crt.CrtError) as e:
+        s.add_obj(str(tmp_path / "nope.obj"), str(tmp_path))
+    assert e.value.status == -5
+    # one vn per v is required (reference Loader.h:70-72 indexes normals with the vertex index)
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nNs 1\n")
+    (tmp_path / "t.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nusemtl a\nf 1/1/1 2/2/2 3/3/3\n")
+    with pytest.raises(crt.CrtError) as e:
+        s.add_obj(str(tmp_path / "t.obj"), str(tmp_path))
+    assert e.value.status == -6
+    with pytest.raises(crt.CrtError) as e:
+        crt.Scene(8, 8).set_BVH(2)  # empty scene
+    assert e.value.status == -1
+    ok = crt.Scene(8, 8)
+    (tmp_path / "t2.obj").write_text("mtllib m.mtl\nv 0 0 0\nvn 0 0 1\nv 1 0 0\nvn 0 0 1\nv 0 1 0\nvn 0 0 1\n"
+                                     "f 1/1/1 2/2/2 3/3/3\nusemtl a\nf 1/1/1 2/2/2 3/3/3\nf 1 3 2\n")
+    ok.add_obj(str(tmp_path / "t2.obj"), str(tmp_path))
+    with pytest.raises(crt.CrtError) as e:
+        ok.set_BVH(0)  # recurses forever in the reference (BVH.h:57-81)
+    assert e.value.status == -1
+    ok.set_BVH(2)
+    # the face before the first usemtl is dropped (OBJLoader.h:120-123); a one-leaf tree is a valid scene
+    assert len(ok.triangles()) == 2 and len(ok.nodes()) == 1 and ok.root == 0
+    o = O.OracleScene([(str(tmp_path / "t2.obj"), str(tmp_path))], 2)
+    assert ok.nodes().tobytes() == o.nodes().tobytes()
+
+
+def test_png_writer_roundtrip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = str(tmp_path / "x.png")
+    capi.check(capi.lib().crt_write_png(path.encode(), 53, 37, capi.ptr(img)), "crt_write_png")
+    assert np.array_equal(np.asarray(Image.open(path)), img)
+    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)  # more than one 64 KiB stored block
+    capi.check(capi.lib().crt_write_png(path.encode(), 400, 300, capi.ptr(big)), "crt_write_png")
+    assert np.array_equal(np.asarray(Image.open(path)), big)
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    header = open(os.path.join(util.ROOT, "include", "crt.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(crt_[a-z_0-9]+)\s*\(", body))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    lib = capi.lib()
+    for name in declared:
+        getattr(lib, name)
+    assert lib.crt_abi_version() == 1
+    assert lib.crt_strerror(-4).decode() == "unsupported"
+
+
+def test_device_entry_points_validate_arguments_without_a_gpu():
+    lib = capi.lib()
+    n = C.c_uint64()
+    capi.check(lib.crt_shard_slots(800, 600, 0, 1, C.byref(n)), "crt_shard_slots")
+    assert n.value == 100 * 75 * 64
+    capi.check(lib.crt_shard_slots(100, 75, 2, 3, C.byref(n)), "crt_shard_slots")
+    assert n.value == ((13 * 10 + 2) // 3) * 64
+    assert lib.crt_shard_slots(0, 75, 0, 1, C.byref(n)) == -1
+    assert lib.crt_shard_slots(8, 8, 3, 3, C.byref(n)) == -1
+    h = C.c_void_p()
+    assert lib.crt_scene_create(None, 0, C.byref(h)) == -1  # invalid description, reported before any device call
+    d = capi.SceneDesc()
+    assert lib.crt_scene_create(C.byref(d), 0, C.byref(h)) == -1
+    assert lib.crt_render(None, None, None, None, None, None) == -1
+    assert b"null" in lib.crt_last_error()
+
+
+def test_cornell_generator_reproduces_committed_obj(tmp_path):
+    out = str(tmp_path / "c.obj")
+    subprocess.check_call([sys.executable, os.path.join(util.ROOT, "scenes", "gen_cornell_box.py"), out],
+                          stdout=subprocess.DEVNULL)
+    a = hashlib.sha256(open(out, "rb").read()).hexdigest()
+    b = hashlib.sha256(open(os.path.join(util.ROOT, "scenes", "cornell-box", "cornell-box.obj"), "rb").read()).hexdigest()
+    assert a == b
