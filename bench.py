@@ -77,11 +77,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    # CRT_BENCH_ONE_DEVICE=1 (testing only): all ranks share cuda:0 and gather over gloo, to exercise the
+    # N > 1 code path on a single-GPU box (RCCL refuses two ranks on one device)
+    one_device = os.environ.get("CRT_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     def barrier():
         if world > 1:
@@ -116,8 +124,9 @@ def main():
         rays_local = st["rays"]
     barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=device)
+    red_dev = torch.device("cpu") if one_device else device
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)

@@ -247,12 +247,195 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
     return L;
 }
 
-// One pass per round, phases in the order every possible chain runs through them
-// (result -> enter vertex -> roulette/bounce -> finish -> regenerate -> next-event setup), so a
-// wave executes each phase at most once however its lanes are distributed over path stages.
-// The kernel is latency bound (a slot's state streams from HBM): every plane is requested up
-// front, the current / previous vertex's normal and material ride along in the pool instead of
-// being re-derived through triangle -> material lookups.
+// One pass of the path state machine for one slot, phases in the order every possible chain runs
+// through them (result -> enter vertex -> roulette/bounce -> finish -> regenerate -> next-event
+// setup), so a wave executes each phase at most once however its lanes are distributed over
+// path stages.  `s` arrives with the slot's state and the ray that produced (res_t, res_tri);
+// returns true if a new ray was emitted into s.ro / s.rd / s.tl / s.kind (false: the slot is dead).
+template <bool LDS_TABLES>
+__device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS_TABLES>& tb, const uint32_t slot, Lane& s, const uint32_t stage,
+                                              const float res_t, const int res_tri, PathCounters& cnt)
+{
+    const DevScene& sc = P.sc;
+    const Pool& pl = P.pool;
+    bool emitted = false;
+    bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
+    int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
+
+    // ---- phase 1: consume the result of the slot's last ray ----
+    if (stage == ST_SHADOW) {
+        // visibility of next-event sample q (Render.cuh:19-27, :272-284)
+        bool blocked = s.tl - res_t > CRT_EPSILON;
+        if (!blocked) s.Ld = add3(s.Ld, s.c);
+        s.q++;
+        if (s.q < (uint32_t)(sc.n_lights * P.lsn)) do_shadow_setup = true; else do_nee_done = true;
+    } else if (stage == ST_HIT) {
+        // the camera / bounce ray that looked for vertex `depth` (Render.cuh:207-213)
+        if (res_tri < 0) {
+            fin_deepest = (int)s.depth - 1; fin_emissive = false;
+            do_finish = true;
+        } else {
+            F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
+            do_enter = true;
+            if (s.depth > 0) {
+                // the previous vertex (normal / material still in the vn plane) is not the deepest one:
+                // cosine of its indirect term (Render.cuh:291)
+                const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
+                F3 pn = s.nrm;
+                float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
+                cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
+                pl.rec_a[pr].w = cos_prev;
+                float4 pm1 = mat_row(tb, s.mat, 1);
+                if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
+                    float ns = mat_row(tb, s.mat, 0).w;
+                    float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
+                    float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
+                    F3 in = unit3(f3(pb.x, pb.y, pb.z));
+                    F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
+                    float d_theta = (float)((double)(delta_coeff * 30) * 3.14159265358979323846 / 180);
+                    float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
+                    U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
+                    F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
+                    // the probe leaves from prev.pos (= this ray's origin); keep the bounce direction for rec_b
+                    pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f);
+                    s.rd = unit3(refd); // Ray.cuh:13
+                    s.tl = 0.0f; s.kind = RAY_CLOSEST;
+                    s.stage = ST_PROBE;
+                    cnt.rays++; cnt.probe++;
+                    emitted = true;
+                    do_enter = false;
+                }
+            }
+            s.pos = pos; s.vtri = (uint32_t)res_tri;
+        }
+    } else if (stage == ST_PROBE) {
+        // the probe ray of vertex depth-1 (Render.cuh:304-313); vn still describes that vertex
+        if (res_tri >= 0) {
+            int hmat = sc.tri_mat[res_tri];
+            float4 q1 = mat_row(tb, hmat, 1);
+            if (__float_as_uint(q1.w) & 1u) {
+                float4 q2 = mat_row(tb, hmat, 2);
+                const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
+                F3 pn = s.nrm;
+                float4 pm0 = mat_row(tb, s.mat, 0), pm1 = mat_row(tb, s.mat, 1);
+                float log_shininess = det_log10f(pm0.w);
+                float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
+                float ip = (float)(2.0f * 3.14159265358979323846) / 8.f;
+                F3 hp = add3(s.ro, scalel3(res_t, s.rd));
+                float ct = dot3(unit3(sub3(hp, s.ro)), pn); // probe origin == prev.pos
+                ct = ct > 0.0f ? ct : 0.0f;
+                // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
+                F3 kekd = mul3(f3(q2.x, q2.y, q2.z), f3(pm1.x, pm1.y, pm1.z));
+                F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
+                float4 a = pl.rec_a[pr];
+                a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
+                pl.rec_a[pr] = a;
+            }
+        }
+        // the bounce direction that found the current vertex was parked in rec_b[depth]
+        float4 pb = pl.rec_b[(size_t)s.depth * pl.n + slot];
+        s.rd = f3(pb.x, pb.y, pb.z);
+        do_enter = true;
+    }
+
+    // ---- phase 2: a new vertex (pos, vtri) at `depth`, reached along s.rd ----
+    F3 f_r = f3(0.0f, 0.0f, 0.0f);
+    if (do_enter) {
+        float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
+        s.nrm = f3(g.y, g.z, g.w);
+        s.mat = (uint32_t)sc.tri_mat[s.vtri];
+        pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
+        float4 m1 = mat_row(tb, s.mat, 1);
+        if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+            float4 m2 = mat_row(tb, s.mat, 2);
+            fin_deepest = (int)s.depth; fin_emissive = true; fin_ke = f3(m2.x, m2.y, m2.z);
+            do_finish = true;
+        } else {
+            s.Ld = f3(0.0f, 0.0f, 0.0f);
+            s.q = 0;
+            if (sc.n_lights * P.lsn > 0) do_shadow_setup = true; else do_nee_done = true;
+        }
+    }
+    if (do_shadow_setup) {
+        float4 m0 = mat_row(tb, s.mat, 0);
+        f_r = f3(m0.x, m0.y, m0.z);
+    }
+
+    // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
+    if (do_nee_done) {
+        pl.rec_a[(size_t)s.depth * pl.n + slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, 0.0f);
+        bool stop = s.depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
+        U4 rb;
+        rb.x = rb.y = rb.z = rb.w = 0;
+        if (!stop) {
+            rb = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_BOUNCE, 0);
+            stop = rng_uniform(rb.x) > P.p_rr;
+        }
+        if (stop) {
+            fin_deepest = (int)s.depth; fin_emissive = false;
+            do_finish = true;
+        } else {
+            F3 ndir = unit3(sample_hemisphere(s.nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
+            s.ro = s.pos;
+            s.rd = unit3(ndir); // Ray.cuh:13
+            s.tl = 0.0f; s.kind = RAY_CLOSEST;
+            s.depth++;
+            s.stage = ST_HIT;
+            cnt.rays++;
+            emitted = true;
+        }
+    }
+
+    // ---- phase 4: path complete ----
+    if (do_finish) {
+        F3 L = finish_path(P, tb, slot, fin_deepest, fin_emissive, fin_ke);
+        P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
+        do_new = true; // regenerate in place
+    }
+
+    // ---- phase 5: take the next work item, camera ray (Render.cuh:344-347) ----
+    if (do_new) {
+        s.stage = ST_DEAD;
+        for (;;) {
+            s.item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, (blockIdx.x * 4u + (threadIdx.x >> 6)) & (ITEM_SHARDS - 1));
+            if (s.item == ITEM_NONE) break;
+            bool valid; uint32_t pi, pj;
+            decode_item(P, s.item, s.pixel_index, s.k, valid, pi, pj);
+            if (!valid) continue; // padding slot of a ragged tile: take another item
+            cnt.paths++;
+            pl.id[slot] = make_uint4(s.pixel_index, s.k, s.item, 0u);
+            U4 rj = rng_draw(P.seed, s.pixel_index, s.k, 0, RNG_JITTER, 0);
+            float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
+            float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
+            F3 cd = unit3(f3(-x, y, 1));
+            F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
+                       P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
+                       P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
+            s.ro = f3(P.eye[0], P.eye[1], P.eye[2]);
+            s.rd = unit3(wd); // Ray.cuh:13
+            s.tl = 0.0f; s.kind = RAY_CLOSEST;
+            s.depth = 0; s.stage = ST_HIT; s.q = 0;
+            cnt.rays++;
+            emitted = true;
+            break;
+        }
+    }
+
+    // ---- phase 6: next-event sample q of the current vertex ----
+    if (do_shadow_setup) {
+        setup_shadow(P, tb, s, f_r);
+        s.stage = ST_SHADOW;
+        cnt.rays++; cnt.shadow++;
+        emitted = true;
+    }
+
+    return emitted;
+}
+
+// Wavefront form: one thread per pool slot and round.  The kernel is latency / bandwidth bound (a
+// slot's state streams from HBM): every plane is requested up front, the current / previous
+// vertex's normal and material ride along in the pool instead of being re-derived through
+// triangle -> material lookups.
 template <bool LDS_TABLES>
 __global__ __launch_bounds__(256) void k_logic(const LParams P)
 {
@@ -297,177 +480,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
         s.rd = f3(rd.x, rd.y, rd.z);
         s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
         s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
-        const float res_t = rs.x;
-        const int res_tri = __float_as_int(rs.y);
-        bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
-        int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
-
-        // ---- phase 1: consume the result of the slot's last ray ----
-        if (stage == ST_SHADOW) {
-            // visibility of next-event sample q (Render.cuh:19-27, :272-284)
-            bool blocked = s.tl - res_t > CRT_EPSILON;
-            if (!blocked) s.Ld = add3(s.Ld, s.c);
-            s.q++;
-            if (s.q < (uint32_t)(sc.n_lights * P.lsn)) do_shadow_setup = true; else do_nee_done = true;
-        } else if (stage == ST_HIT) {
-            // the camera / bounce ray that looked for vertex `depth` (Render.cuh:207-213)
-            if (res_tri < 0) {
-                fin_deepest = (int)s.depth - 1; fin_emissive = false;
-                do_finish = true;
-            } else {
-                F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
-                do_enter = true;
-                if (s.depth > 0) {
-                    // the previous vertex (normal / material still in the vn plane) is not the deepest one:
-                    // cosine of its indirect term (Render.cuh:291)
-                    const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
-                    F3 pn = s.nrm;
-                    float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
-                    cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
-                    pl.rec_a[pr].w = cos_prev;
-                    float4 pm1 = mat_row(tb, s.mat, 1);
-                    if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
-                        float ns = mat_row(tb, s.mat, 0).w;
-                        float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
-                        float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
-                        F3 in = unit3(f3(pb.x, pb.y, pb.z));
-                        F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
-                        float d_theta = (float)((double)(delta_coeff * 30) * 3.14159265358979323846 / 180);
-                        float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
-                        U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
-                        F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
-                        // the probe leaves from prev.pos (= this ray's origin); keep the bounce direction for rec_b
-                        pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f);
-                        s.rd = unit3(refd); // Ray.cuh:13
-                        s.tl = 0.0f; s.kind = RAY_CLOSEST;
-                        s.stage = ST_PROBE;
-                        cnt.rays++; cnt.probe++;
-                        emitted = true;
-                        do_enter = false;
-                    }
-                }
-                s.pos = pos; s.vtri = (uint32_t)res_tri;
-            }
-        } else if (stage == ST_PROBE) {
-            // the probe ray of vertex depth-1 (Render.cuh:304-313); vn still describes that vertex
-            if (res_tri >= 0) {
-                int hmat = sc.tri_mat[res_tri];
-                float4 q1 = mat_row(tb, hmat, 1);
-                if (__float_as_uint(q1.w) & 1u) {
-                    float4 q2 = mat_row(tb, hmat, 2);
-                    const size_t pr = (size_t)(s.depth - 1) * pl.n + slot;
-                    F3 pn = s.nrm;
-                    float4 pm0 = mat_row(tb, s.mat, 0), pm1 = mat_row(tb, s.mat, 1);
-                    float log_shininess = det_log10f(pm0.w);
-                    float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
-                    float ip = (float)(2.0f * 3.14159265358979323846) / 8.f;
-                    F3 hp = add3(s.ro, scalel3(res_t, s.rd));
-                    float ct = dot3(unit3(sub3(hp, s.ro)), pn); // probe origin == prev.pos
-                    ct = ct > 0.0f ? ct : 0.0f;
-                    // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
-                    F3 kekd = mul3(f3(q2.x, q2.y, q2.z), f3(pm1.x, pm1.y, pm1.z));
-                    F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
-                    float4 a = pl.rec_a[pr];
-                    a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
-                    pl.rec_a[pr] = a;
-                }
-            }
-            // the bounce direction that found the current vertex was parked in rec_b[depth]
-            float4 pb = pl.rec_b[(size_t)s.depth * pl.n + slot];
-            s.rd = f3(pb.x, pb.y, pb.z);
-            do_enter = true;
-        }
-
-        // ---- phase 2: a new vertex (pos, vtri) at `depth`, reached along s.rd ----
-        F3 f_r = f3(0.0f, 0.0f, 0.0f);
-        if (do_enter) {
-            float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
-            s.nrm = f3(g.y, g.z, g.w);
-            s.mat = (uint32_t)sc.tri_mat[s.vtri];
-            pl.rec_b[(size_t)s.depth * pl.n + slot] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
-            float4 m1 = mat_row(tb, s.mat, 1);
-            if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
-                float4 m2 = mat_row(tb, s.mat, 2);
-                fin_deepest = (int)s.depth; fin_emissive = true; fin_ke = f3(m2.x, m2.y, m2.z);
-                do_finish = true;
-            } else {
-                s.Ld = f3(0.0f, 0.0f, 0.0f);
-                s.q = 0;
-                if (sc.n_lights * P.lsn > 0) do_shadow_setup = true; else do_nee_done = true;
-            }
-        }
-        if (do_shadow_setup) {
-            float4 m0 = mat_row(tb, s.mat, 0);
-            f_r = f3(m0.x, m0.y, m0.z);
-        }
-
-        // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
-        if (do_nee_done) {
-            pl.rec_a[(size_t)s.depth * pl.n + slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, 0.0f);
-            bool stop = s.depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
-            U4 rb;
-            rb.x = rb.y = rb.z = rb.w = 0;
-            if (!stop) {
-                rb = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_BOUNCE, 0);
-                stop = rng_uniform(rb.x) > P.p_rr;
-            }
-            if (stop) {
-                fin_deepest = (int)s.depth; fin_emissive = false;
-                do_finish = true;
-            } else {
-                F3 ndir = unit3(sample_hemisphere(s.nrm, rng_uniform(rb.y), rng_uniform(rb.z)));
-                s.ro = s.pos;
-                s.rd = unit3(ndir); // Ray.cuh:13
-                s.tl = 0.0f; s.kind = RAY_CLOSEST;
-                s.depth++;
-                s.stage = ST_HIT;
-                cnt.rays++;
-                emitted = true;
-            }
-        }
-
-        // ---- phase 4: path complete ----
-        if (do_finish) {
-            F3 L = finish_path(P, tb, slot, fin_deepest, fin_emissive, fin_ke);
-            P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
-            do_new = true; // regenerate in place
-        }
-
-        // ---- phase 5: take the next work item, camera ray (Render.cuh:344-347) ----
-        if (do_new) {
-            s.stage = ST_DEAD;
-            for (;;) {
-                s.item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, (blockIdx.x * 4u + (threadIdx.x >> 6)) & (ITEM_SHARDS - 1));
-                if (s.item == ITEM_NONE) break;
-                bool valid; uint32_t pi, pj;
-                decode_item(P, s.item, s.pixel_index, s.k, valid, pi, pj);
-                if (!valid) continue; // padding slot of a ragged tile: take another item
-                cnt.paths++;
-                pl.id[slot] = make_uint4(s.pixel_index, s.k, s.item, 0u);
-                U4 rj = rng_draw(P.seed, s.pixel_index, s.k, 0, RNG_JITTER, 0);
-                float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
-                float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
-                F3 cd = unit3(f3(-x, y, 1));
-                F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
-                           P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
-                           P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
-                s.ro = f3(P.eye[0], P.eye[1], P.eye[2]);
-                s.rd = unit3(wd); // Ray.cuh:13
-                s.tl = 0.0f; s.kind = RAY_CLOSEST;
-                s.depth = 0; s.stage = ST_HIT; s.q = 0;
-                cnt.rays++;
-                emitted = true;
-                break;
-            }
-        }
-
-        // ---- phase 6: next-event sample q of the current vertex ----
-        if (do_shadow_setup) {
-            setup_shadow(P, tb, s, f_r);
-            s.stage = ST_SHADOW;
-            cnt.rays++; cnt.shadow++;
-            emitted = true;
-        }
+        emitted = logic_advance(P, tb, slot, s, stage, rs.x, __float_as_int(rs.y), cnt);
 
         // ---- write the slot back ----
         st = s.depth | (s.stage << 8) | (s.q << 16);
@@ -561,6 +574,119 @@ __device__ __forceinline__ int trav_pop(TravLane& L, const TravStack& S)
     return 1;
 }
 
+// One wave-wide traversal step: pop phase, then either the leaf phase (when enough lanes hold a
+// leaf, or nobody has inner work) or the inner-node phase.  Returns true in lanes whose ray is
+// finished (result in L.best_t / L.best_tri); nothing_to_do = no lane had any traversal work.
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& state, const TravStack& S, const int leaf_min,
+                                          TravCounters& cnt, uint32_t& ray_sp, bool& nothing_to_do)
+{
+    bool finished = false;
+    // ---- pop phase: lanes whose subtree is exhausted take the next pending node ----
+    if (state == TR_POP) {
+        int r = trav_pop<MODE>(L, S);
+        if (r == 0) finished = true;
+        else if (r == 1) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+    }
+    const int n_inner = __popcll(__ballot(state == TR_INNER));
+    const int n_leaf = __popcll(__ballot(state == TR_LEAF));
+    const int n_pop = __popcll(__ballot(state == TR_POP && !finished));
+    nothing_to_do = n_inner == 0 && n_leaf == 0 && n_pop == 0 && __ballot(finished) == 0;
+    if (nothing_to_do) return false;
+    if (n_leaf > 0 && (n_leaf >= leaf_min || n_inner == 0)) {
+        // ---- leaf phase ----
+        if (state == TR_LEAF) {
+            if (STATS) cnt.leaf++;
+            uint32_t code = (uint32_t)~L.ref;
+            int it = (int)(code >> 4);
+            int n = (int)(code & 15u);
+            if (n == 0) n = sc.leaf_count[it];
+            bool done = false;
+            for (int i = it; i < it + n; i++) {
+                if (STATS) cnt.tests++;
+                float t;
+                if (tri_test(sc, i, L.r, t)) {
+                    if (L.any_hit) {
+                        if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; break; }
+                    } else if (t < L.best_t || (t == L.best_t && it > L.best_leaf)) {
+                        L.best_t = t; L.best_tri = i; L.best_leaf = it;
+                        if (MODE == 0) L.bound = prune_bound(t);
+                    }
+                }
+            }
+            if (done) finished = true;
+            else {
+                int r = trav_pop<MODE>(L, S);
+                if (r == 0) finished = true;
+                else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
+            }
+        }
+    } else if (n_inner > 0) {
+        // ---- inner phase ----
+        if (state == TR_INNER) {
+            if (STATS) cnt.inner++;
+            const float4* n = sc.nodes + (size_t)L.ref * 4;
+            float4 a = n[0], b = n[1], c = n[2], d = n[3];
+            float tl, tr;
+            bool hl = slab_test(a, b, L.r, L.nx, L.ny, L.nz, tl);
+            bool hr = slab_test(c, d, L.r, L.nx, L.ny, L.nz, tr);
+            int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
+            bool have = true;
+            if (MODE == 1) {
+                // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
+                if (hl && hr) { trav_push(S, L.sp, lref, 0.0f); L.sp++; L.ref = rref; }
+                else if (hl) L.ref = lref;
+                else if (hr) L.ref = rref;
+                else have = false;
+            } else {
+                hl = hl && !(tl > L.bound);
+                hr = hr && !(tr > L.bound);
+                if (hl && hr) {
+                    bool left_first = tl <= tr;
+                    trav_push(S, L.sp, left_first ? rref : lref, left_first ? tr : tl);
+                    L.sp++;
+                    L.ref = left_first ? lref : rref;
+                } else if (hl) L.ref = lref;
+                else if (hr) L.ref = rref;
+                else have = false;
+            }
+            if (STATS && (uint32_t)L.sp > ray_sp) ray_sp = (uint32_t)L.sp;
+            if (have) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+            else {
+                int r = trav_pop<MODE>(L, S);
+                if (r == 0) finished = true;
+                else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
+            }
+        }
+    }
+    return finished;
+}
+
+// Starts the traversal of the ray in L.r (origin, direction): returns the lane's new state, TR_IDLE
+// if the answer is known without traversal (result already in L.best_t / L.best_tri).
+template <int MODE>
+__device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint32_t kind, float t_limit)
+{
+    L.r.inv = f3(1 / L.r.d.x, 1 / L.r.d.y, 1 / L.r.d.z); // Ray.cuh:14
+    L.nx = L.r.d.x < 0; L.ny = L.r.d.y < 0; L.nz = L.r.d.z < 0;
+    L.t_limit = t_limit;
+    // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
+    L.any_hit = MODE == 0 && kind == RAY_SHADOW;
+    L.best_t = FLT_MAX; L.best_tri = -1; L.best_leaf = -1;
+    L.bound = FLT_MAX;
+    L.sp = 0;
+    // rays with a zero / denormal direction component (inv_dir not finite) can put NaNs into the
+    // slab test; they walk the reference topology, whose box tests are the reference's own (crt_accel.h)
+    const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
+    L.ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
+    if (L.any_hit) {
+        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
+        if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) return TR_IDLE;
+        L.bound = prune_bound(L.t_limit);
+    }
+    return L.ref >= 0 ? TR_INNER : TR_LEAF;
+}
+
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_trace(const TParams T)
 {
@@ -632,110 +758,16 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
                     L.slot = my;
                     L.r.o = f3(ro.x, ro.y, ro.z);
                     L.r.d = f3(rd.x, rd.y, rd.z);
-                    L.r.inv = f3(1 / L.r.d.x, 1 / L.r.d.y, 1 / L.r.d.z); // Ray.cuh:14
-                    L.nx = L.r.d.x < 0; L.ny = L.r.d.y < 0; L.nz = L.r.d.z < 0;
-                    L.t_limit = ro.w;
-                    // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
-                    L.any_hit = MODE == 0 && kind == RAY_SHADOW;
-                    L.best_t = FLT_MAX; L.best_tri = -1; L.best_leaf = -1;
-                    L.bound = FLT_MAX;
-                    L.sp = 0;
-                    // rays with a zero / denormal direction component (inv_dir not finite) can put NaNs into the
-                    // slab test; they walk the reference topology, whose box tests are the reference's own (crt_accel.h)
-                    const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
-                    L.ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
-                    state = L.ref >= 0 ? TR_INNER : TR_LEAF;
-                    if (L.any_hit) {
-                        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
-                        if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) {
-                            pl.res[my] = make_float2(FLT_MAX, __int_as_float(-1));
-                            state = TR_IDLE;
-                        } else {
-                            L.bound = prune_bound(L.t_limit);
-                        }
-                    }
+                    state = trav_begin<MODE>(sc, L, kind, ro.w);
+                    if (state == TR_IDLE) pl.res[my] = make_float2(FLT_MAX, __int_as_float(-1));
                 }
             }
         }
-        bool finished = false;
-        // ---- pop phase: lanes whose subtree is exhausted take the next pending node ----
-        if (state == TR_POP) {
-            int r = trav_pop<MODE>(L, S);
-            if (r == 0) finished = true;
-            else if (r == 1) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
-        }
-        const int n_inner = __popcll(__ballot(state == TR_INNER));
-        const int n_leaf = __popcll(__ballot(state == TR_LEAF));
-        const int n_pop = __popcll(__ballot(state == TR_POP && !finished));
-        if (n_inner == 0 && n_leaf == 0 && n_pop == 0 && __ballot(finished) == 0) {
+        bool nothing_to_do = false;
+        const bool finished = trav_step<MODE, STATS>(sc, L, state, S, T.leaf_min, cnt, ray_sp, nothing_to_do);
+        if (nothing_to_do) {
             if (exhausted) break;
             continue; // every lane is idle: the next iteration refills
-        }
-        if (n_leaf > 0 && (n_leaf >= T.leaf_min || n_inner == 0)) {
-            // ---- leaf phase ----
-            if (state == TR_LEAF) {
-                if (STATS) cnt.leaf++;
-                uint32_t code = (uint32_t)~L.ref;
-                int it = (int)(code >> 4);
-                int n = (int)(code & 15u);
-                if (n == 0) n = sc.leaf_count[it];
-                bool done = false;
-                for (int i = it; i < it + n; i++) {
-                    if (STATS) cnt.tests++;
-                    float t;
-                    if (tri_test(sc, i, L.r, t)) {
-                        if (L.any_hit) {
-                            if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; break; }
-                        } else if (t < L.best_t || (t == L.best_t && it > L.best_leaf)) {
-                            L.best_t = t; L.best_tri = i; L.best_leaf = it;
-                            if (MODE == 0) L.bound = prune_bound(t);
-                        }
-                    }
-                }
-                if (done) finished = true;
-                else {
-                    int r = trav_pop<MODE>(L, S);
-                    if (r == 0) finished = true;
-                    else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
-                }
-            }
-        } else if (n_inner > 0) {
-            // ---- inner phase ----
-            if (state == TR_INNER) {
-                if (STATS) cnt.inner++;
-                const float4* n = sc.nodes + (size_t)L.ref * 4;
-                float4 a = n[0], b = n[1], c = n[2], d = n[3];
-                float tl, tr;
-                bool hl = slab_test(a, b, L.r, L.nx, L.ny, L.nz, tl);
-                bool hr = slab_test(c, d, L.r, L.nx, L.ny, L.nz, tr);
-                int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-                bool have = true;
-                if (MODE == 1) {
-                    // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
-                    if (hl && hr) { trav_push(S, L.sp, lref, 0.0f); L.sp++; L.ref = rref; }
-                    else if (hl) L.ref = lref;
-                    else if (hr) L.ref = rref;
-                    else have = false;
-                } else {
-                    hl = hl && !(tl > L.bound);
-                    hr = hr && !(tr > L.bound);
-                    if (hl && hr) {
-                        bool left_first = tl <= tr;
-                        trav_push(S, L.sp, left_first ? rref : lref, left_first ? tr : tl);
-                        L.sp++;
-                        L.ref = left_first ? lref : rref;
-                    } else if (hl) L.ref = lref;
-                    else if (hr) L.ref = rref;
-                    else have = false;
-                }
-                if (STATS && (uint32_t)L.sp > ray_sp) ray_sp = (uint32_t)L.sp;
-                if (have) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
-                else {
-                    int r = trav_pop<MODE>(L, S);
-                    if (r == 0) finished = true;
-                    else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
-                }
-            }
         }
         if (finished) {
             if (STATS) {
@@ -763,6 +795,151 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
         for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
         if (lane == 0) {
             unsigned long long* cs = T.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+            atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
+            atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
+        }
+    }
+}
+
+// ------------------------------------------------------------ megakernel ----
+// Fused form of the two kernels above: one persistent launch per chunk.  Every lane owns one
+// path slot for the whole launch (slot = global thread id, so all plane accesses are perfectly
+// coalesced); when its ray finishes the lane parks, and as soon as MEGA_LOGIC_MIN lanes of the
+// wave are parked they run logic_advance together and re-enter the traversal with the new ray
+// in registers.  Rays and results never touch memory, there are no rounds, no relaunches and no
+// per-round drain; the path state planes (80 B per lane + 32 B vertex records) stay L2 / MALL
+// resident because there are only as many slots as resident lanes.
+struct MParams {
+    LParams P;
+    DevScene sc;
+    unsigned long long* counters;
+    int2* spill;
+    uint32_t spill_stride;
+    int32_t stack_cap;
+    int32_t logic_min, leaf_min;
+};
+
+template <int MODE, bool STATS, bool LDS_TABLES>
+__global__ __launch_bounds__(256) void k_mega(const MParams M)
+{
+    extern __shared__ int2 s_lds2[];
+    const LParams& P = M.P;
+    const DevScene& sc = M.sc;
+    const Pool& pl = P.pool;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t slot = blockIdx.x * 256u + tid;
+    __shared__ uint32_t s_cnt[5];
+    __shared__ float4 s_mats[LDS_TABLES ? LOGIC_TABLE_MAX * 3 : 1];
+    __shared__ uint2 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
+    Tables<LDS_TABLES> tb;
+    if (LDS_TABLES) {
+        if (threadIdx.x < (uint32_t)P.n_mats * 3u) s_mats[threadIdx.x] = sc.mats[threadIdx.x];
+        if (threadIdx.x < (uint32_t)sc.n_lights) s_lights[threadIdx.x] = sc.lights[threadIdx.x];
+        tb.mats = s_mats; tb.lights = s_lights;
+    } else {
+        tb.mats = sc.mats; tb.lights = sc.lights;
+    }
+    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    TravStack S;
+    S.lds = s_lds2 + tid;
+    S.spill = M.spill + slot;
+    S.spill_stride = M.spill_stride;
+    S.cap = M.stack_cap;
+
+    PathCounters cnt;
+    cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
+    TravCounters tc;
+    tc.inner = tc.leaf = tc.tests = tc.hits = 0;
+    uint32_t max_sp = 0, sum_sp = 0, ray_sp = 0;
+
+    int state = TR_IDLE;
+    bool dead = slot >= pl.n;
+    uint32_t stage = ST_NEW; // stage the parked lane is in (what its last ray was for)
+    TravLane L;
+    L.slot = slot; L.ref = 0; L.sp = 0; L.best_tri = -1; L.best_leaf = -1; L.best_t = FLT_MAX; L.bound = FLT_MAX; L.t_limit = 0.0f;
+    L.any_hit = false; L.nx = L.ny = L.nz = false;
+    L.r.o = L.r.d = L.r.inv = f3(0.0f, 0.0f, 0.0f);
+
+    for (;;) {
+        // ---- path logic for parked lanes, batched ----
+        const unsigned long long parked = __ballot(state == TR_IDLE && !dead);
+        const unsigned long long busy = __ballot(state != TR_IDLE);
+        if (parked == 0 && busy == 0) break; // every lane of the wave is dead
+        if (__popcll(parked) >= M.logic_min || busy == 0) {
+            if (state == TR_IDLE && !dead) {
+                Lane s;
+                s.stage = stage;
+                s.kind = RAY_NONE;
+                s.ro = L.r.o; s.rd = L.r.d; s.tl = L.t_limit;
+                s.Ld = s.c = s.pos = s.nrm = f3(0.0f, 0.0f, 0.0f);
+                s.depth = 0; s.q = 0; s.vtri = 0; s.mat = 0; s.pixel_index = 0; s.k = 0; s.item = ITEM_NONE;
+                if (stage != ST_NEW) {
+                    float4 la = pl.la[slot], cc = pl.cc[slot], vx = pl.vx[slot], vn = pl.vn[slot];
+                    uint4 idv = pl.id[slot];
+                    uint32_t st = __float_as_uint(la.w);
+                    s.depth = st & 255u; s.q = st >> 16;
+                    s.Ld = f3(la.x, la.y, la.z);
+                    s.c = f3(cc.x, cc.y, cc.z);
+                    s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
+                    s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
+                    s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
+                }
+                const bool emitted = logic_advance(P, tb, slot, s, stage, L.best_t, L.best_tri, cnt);
+                if (emitted) {
+                    uint32_t st = s.depth | (s.stage << 8) | (s.q << 16);
+                    pl.la[slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(st));
+                    if (s.stage == ST_SHADOW) pl.cc[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+                    if (stage != ST_SHADOW) {
+                        pl.vx[slot] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
+                        pl.vn[slot] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
+                    }
+                    stage = s.stage;
+                    L.r.o = s.ro; L.r.d = s.rd;
+                    state = trav_begin<MODE>(sc, L, s.kind, s.tl); // TR_IDLE: answered without traversal, parks again
+                } else {
+                    dead = true;
+                }
+            }
+            continue; // re-evaluate: lanes answered without traversal are parked again
+        }
+        // ---- one traversal step for the lanes in flight ----
+        bool nothing_to_do = false;
+        const bool finished = trav_step<MODE, STATS>(sc, L, state, S, M.leaf_min, tc, ray_sp, nothing_to_do);
+        if (finished) {
+            if (STATS) {
+                if (L.best_tri >= 0) tc.hits++;
+                if (ray_sp > max_sp) max_sp = ray_sp;
+                sum_sp += ray_sp;
+                ray_sp = 0;
+            }
+            state = TR_IDLE;
+        }
+    }
+
+    // ---- counters ----
+    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
+    if (lane == 0 && (r | pa)) {
+        atomicAdd(&s_cnt[0], r); atomicAdd(&s_cnt[1], sh); atomicAdd(&s_cnt[2], pr); atomicAdd(&s_cnt[3], pa);
+    }
+    __syncthreads();
+    unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) {
+        const int idx[4] = {C_RAYS, C_SHADOW, C_PROBE, C_PATHS};
+        atomicAdd(&cs[idx[threadIdx.x]], (unsigned long long)s_cnt[threadIdx.x]);
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(tc.inner), b = wave_sum(tc.leaf), c = wave_sum(tc.tests), d = wave_sum(tc.hits);
+        uint32_t ss = wave_sum(sum_sp);
+        uint32_t ms = max_sp;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
+        if (lane == 0) {
+            atomicAdd(&cs[C_INNER], (unsigned long long)a);
+            atomicAdd(&cs[C_LEAF], (unsigned long long)b);
+            atomicAdd(&cs[C_TESTS], (unsigned long long)c);
+            atomicAdd(&cs[C_HITS], (unsigned long long)d);
             atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
             atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
         }
@@ -1178,6 +1355,112 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             return v;
         };
         unsigned long long alive_seen = 0;
+
+        if (env_u32("CRT_PIPELINE", 1) == 1) {
+            // ---------- fused persistent megakernel: one launch per chunk ----------
+            const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
+            const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
+            const size_t lds = (size_t)lds_cap * 256 * sizeof(int2);
+            const bool lds_tables = sc->n_mats <= LOGIC_TABLE_MAX && (uint32_t)sc->dev.n_lights <= LOGIC_TABLE_MAX;
+            const int mode_id = (reference ? 2 : 0) + (want_stats ? 1 : 0);
+            auto launch_mega = [&](const MParams& M, uint32_t blocks, bool query, int* per_cu) {
+#define CRT_MEGA_CASE(MODE, STATS, TBL)                                                                                        \
+    if (query) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_mega<MODE, STATS, TBL>, 256, lds) != hipSuccess) *per_cu = 1; } \
+    else hipLaunchKernelGGL((k_mega<MODE, STATS, TBL>), dim3(blocks), dim3(256), lds, st, M);
+                if (lds_tables) {
+                    if (mode_id == 0) { CRT_MEGA_CASE(0, false, true) } else if (mode_id == 1) { CRT_MEGA_CASE(0, true, true) }
+                    else if (mode_id == 2) { CRT_MEGA_CASE(1, false, true) } else { CRT_MEGA_CASE(1, true, true) }
+                } else {
+                    if (mode_id == 0) { CRT_MEGA_CASE(0, false, false) } else if (mode_id == 1) { CRT_MEGA_CASE(0, true, false) }
+                    else if (mode_id == 2) { CRT_MEGA_CASE(1, false, false) } else { CRT_MEGA_CASE(1, true, false) }
+                }
+#undef CRT_MEGA_CASE
+            };
+            MParams M;
+            std::memset(&M, 0, sizeof(M));
+            int per_cu = 1;
+            launch_mega(M, 0, true, &per_cu);
+            per_cu = (int)std::min<uint32_t>((uint32_t)std::max(1, per_cu), env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
+            const uint32_t blocks = std::min<uint32_t>((uint32_t)((cap + 255) / 256), (uint32_t)(sc->n_cus * per_cu));
+            const uint32_t lanes = blocks * 256u;
+            sc->p_vx.ensure(lanes); sc->p_la.ensure(lanes); sc->p_cc.ensure(lanes); sc->p_vn.ensure(lanes); sc->p_id.ensure(lanes);
+            sc->p_rec_a.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
+            sc->p_rec_b.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
+            const int spill_levels = std::max(1, sc->stack_cap - lds_cap);
+            sc->spill[0].ensure((size_t)spill_levels * lanes);
+            Pool pool;
+            std::memset(&pool, 0, sizeof(pool));
+            pool.vx = sc->p_vx.p; pool.la = sc->p_la.p; pool.cc = sc->p_cc.p; pool.vn = sc->p_vn.p; pool.id = sc->p_id.p;
+            pool.rec_a = sc->p_rec_a.p; pool.rec_b = sc->p_rec_b.p; pool.n = lanes;
+            LParams P;
+            std::memset(&P, 0, sizeof(P));
+            P.sc = sc->dev; P.pool = pool;
+            std::memcpy(P.eye, cam->eye, sizeof(P.eye));
+            std::memcpy(P.inv_view, cam->inv_view, sizeof(P.inv_view));
+            P.scale = det_tanf(cam->fov_y / 2);                       // Render.cuh:338
+            P.ar = (float)prm->width / (float)prm->height;            // Render.cuh:339
+            P.width = prm->width; P.height = prm->height;
+            P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
+            P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
+            P.nslots = sh.nslots;
+            P.L = sc->L.p; P.counters = sc->counters.p; P.item_next = sc->item_next.p; P.n_mats = sc->n_mats;
+            M.sc = sc->dev; M.counters = sc->counters.p; M.spill = sc->spill[0].p; M.spill_stride = lanes; M.stack_cap = lds_cap;
+            M.logic_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LOGIC_MIN", 32));
+            M.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", LEAF_MIN));
+            AParams A;
+            std::memset(&A, 0, sizeof(A));
+            A.width = prm->width; A.height = prm->height; A.spp = prm->spp;
+            A.rank = prm->rank; A.world = prm->world; A.tiles_x = sh.tiles_x; A.n_tiles = sh.n_tiles;
+            A.nslots = sh.nslots; A.tiled_output = tiled ? 1 : 0;
+            A.L = sc->L.p; A.accum = sc->accum.p;
+            A.out_rgb = (uint8_t*)d_rgb; A.out_mean = (float*)d_mean;
+            hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+            if (timing) { e0 = sc->ev[0]; e1 = sc->ev[1]; e2 = sc->ev[2]; e3 = sc->ev[3]; HIP_CHECK(hipEventRecord(e0, st)); }
+            double kernel_ms = 0.0;
+            uint32_t launches = 0;
+            for (uint32_t s0 = 0; s0 < prm->spp; s0 += chunk) {
+                uint32_t ns = std::min(chunk, prm->spp - s0);
+                P.sample_begin = s0;
+                P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
+                P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
+                M.P = P;
+                HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
+                if (timing) HIP_CHECK(hipEventRecord(e1, st));
+                launch_mega(M, blocks, false, nullptr);
+                HIP_CHECK(hipGetLastError());
+                if (timing) {
+                    HIP_CHECK(hipEventRecord(e2, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    float ms = 0.0f;
+                    HIP_CHECK(hipEventElapsedTime(&ms, e1, e2));
+                    kernel_ms += ms;
+                }
+                launches++;
+                A.chunk_samples = ns;
+                A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
+                hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
+                HIP_CHECK(hipGetLastError());
+            }
+            if (stats) {
+                HIP_CHECK(hipEventRecord(e3, st));
+                HIP_CHECK(hipMemcpyAsync(sc->h_counters, sc->counters.p, counters_bytes, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                std::memset(stats, 0, sizeof(*stats));
+                stats->paths = counter_sum(C_PATHS); stats->rays = counter_sum(C_RAYS); stats->shadow_rays = counter_sum(C_SHADOW);
+                stats->probe_rays = counter_sum(C_PROBE);
+                stats->inner_pops = counter_sum(C_INNER); stats->leaf_pops = counter_sum(C_LEAF); stats->tri_tests = counter_sum(C_TESTS);
+                stats->hits = counter_sum(C_HITS);
+                stats->stack_sum = counter_sum(C_SUMSP);
+                for (int sh2 = 0; sh2 < CNT_SHARDS; sh2++) stats->stack_max = std::max<uint64_t>(stats->stack_max, sc->h_counters[sh2 * CNT_STRIDE + C_MAXSP]);
+                float total = 0.0f;
+                HIP_CHECK(hipEventElapsedTime(&total, e0, e3));
+                stats->kernel_ms = (float)kernel_ms;
+                stats->logic_ms = 0.0f;
+                stats->total_ms = total;
+                stats->kernel_launches = launches;
+            }
+            return CRT_OK;
+        }
 
         // The pool is split into halves that run on two streams: the HBM-bound k_logic of one half
         // overlaps the issue-bound k_trace of the other.

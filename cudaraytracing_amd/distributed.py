@@ -67,8 +67,13 @@ def gather_image(local, width, height, world, group=None):
     import torch
     import torch.distributed as dist
     if world > 1:
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered.view(-1), local.reshape(-1), group=group)
+        if dist.get_backend(group) == "gloo" and local.is_cuda:  # test configuration only: gloo gathers host tensors
+            host = torch.empty((world,) + tuple(local.shape), dtype=local.dtype)
+            dist.all_gather_into_tensor(host.view(-1), local.cpu().reshape(-1), group=group)
+            gathered = host.to(local.device)
+        else:
+            gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(gathered.view(-1), local.reshape(-1), group=group)
     else:
         gathered = local.unsqueeze(0)
     return untile_torch(gathered, width, height)
