@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libcrt.so")
 CLI = os.path.join(LIBDIR, "crt_cli")
 
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"] + os.environ.get("CRT_EXTRA_CXXFLAGS", "").split()
 DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
 LIB_SOURCES = ["crt_kernels.hip", "crt_host.cpp"]

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_pool_init(Pool pl)
 #define TR_LEAF 2
 #define TR_POP 3
 #define REFILL_MIN 32
-#define LEAF_MIN 16
+#define LEAF_MIN 24
 #define SLOT_SHARDS 64
 #define SLOT_STRIDE 32
 
@@ -577,6 +577,9 @@ __device__ __forceinline__ int trav_pop(TravLane& L, const TravStack& S)
 // One wave-wide traversal step: pop phase, then either the leaf phase (when enough lanes hold a
 // leaf, or nobody has inner work) or the inner-node phase.  Returns true in lanes whose ray is
 // finished (result in L.best_t / L.best_tri); nothing_to_do = no lane had any traversal work.
+// The bodies are written with selects instead of nested branches: every divergent `if` costs
+// several scalar instructions of exec-mask bookkeeping, and rocprof shows the scalar unit almost
+// as busy as the vector units in this kernel.
 template <int MODE, bool STATS>
 __device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& state, const TravStack& S, const int leaf_min,
                                           TravCounters& cnt, uint32_t& ray_sp, bool& nothing_to_do)
@@ -585,41 +588,59 @@ __device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& 
     // ---- pop phase: lanes whose subtree is exhausted take the next pending node ----
     if (state == TR_POP) {
         int r = trav_pop<MODE>(L, S);
-        if (r == 0) finished = true;
-        else if (r == 1) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
+        finished = r == 0;
+        state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
     }
     const int n_inner = __popcll(__ballot(state == TR_INNER));
     const int n_leaf = __popcll(__ballot(state == TR_LEAF));
     const int n_pop = __popcll(__ballot(state == TR_POP && !finished));
     nothing_to_do = n_inner == 0 && n_leaf == 0 && n_pop == 0 && __ballot(finished) == 0;
     if (nothing_to_do) return false;
+    bool need_pop = false;
     if (n_leaf > 0 && (n_leaf >= leaf_min || n_inner == 0)) {
         // ---- leaf phase ----
         if (state == TR_LEAF) {
-            if (STATS) cnt.leaf++;
             uint32_t code = (uint32_t)~L.ref;
-            int it = (int)(code >> 4);
+            const int it = (int)(code >> 4);
             int n = (int)(code & 15u);
             if (n == 0) n = sc.leaf_count[it];
+            // the first two triangles in straight-line code (the reference's bvh_thresh_n = 2 gives 1-2 per leaf):
+            // both fetches are in flight together, nothing branches
+            const bool two = n > 1;
+            float t0, t1;
+            const bool a0 = tri_test(sc, it, L.r, t0);
+            const bool a1 = tri_test(sc, two ? it + 1 : it, L.r, t1) && two;
+            if (STATS) { cnt.leaf++; cnt.tests += two ? 2u : 1u; }
             bool done = false;
-            for (int i = it; i < it + n; i++) {
+            if (L.any_hit) {
+                const bool b0 = a0 && (L.t_limit - t0 > CRT_EPSILON);
+                const bool b1 = a1 && (L.t_limit - t1 > CRT_EPSILON);
+                done = b0 || b1;
+                L.best_t = b0 ? t0 : (b1 ? t1 : L.best_t);
+                L.best_tri = b0 ? it : (b1 ? it + 1 : L.best_tri);
+            } else {
+                // ascending index, strict <: the first of equal t inside a leaf wins (DeviceBVH.cuh:34-41); across leaves the
+                // larger leaf start wins (reference visit order, see crt_trace.h)
+                const bool w0 = a0 && (t0 < L.best_t || (t0 == L.best_t && it > L.best_leaf));
+                L.best_t = w0 ? t0 : L.best_t; L.best_tri = w0 ? it : L.best_tri; L.best_leaf = w0 ? it : L.best_leaf;
+                const bool w1 = a1 && (t1 < L.best_t || (t1 == L.best_t && it > L.best_leaf));
+                L.best_t = w1 ? t1 : L.best_t; L.best_tri = w1 ? it + 1 : L.best_tri; L.best_leaf = w1 ? it : L.best_leaf;
+                if (MODE == 0) L.bound = (w0 || w1) ? prune_bound(L.best_t) : L.bound;
+            }
+            for (int i = it + 2; i < it + n && !done; i++) { // only with bvh_thresh_n > 2
                 if (STATS) cnt.tests++;
                 float t;
                 if (tri_test(sc, i, L.r, t)) {
                     if (L.any_hit) {
-                        if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; break; }
+                        if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; }
                     } else if (t < L.best_t || (t == L.best_t && it > L.best_leaf)) {
                         L.best_t = t; L.best_tri = i; L.best_leaf = it;
                         if (MODE == 0) L.bound = prune_bound(t);
                     }
                 }
             }
-            if (done) finished = true;
-            else {
-                int r = trav_pop<MODE>(L, S);
-                if (r == 0) finished = true;
-                else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
-            }
+            finished = done;
+            need_pop = !done;
         }
     } else if (n_inner > 0) {
         // ---- inner phase ----
@@ -630,34 +651,31 @@ __device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& 
             float tl, tr;
             bool hl = slab_test(a, b, L.r, L.nx, L.ny, L.nz, tl);
             bool hr = slab_test(c, d, L.r, L.nx, L.ny, L.nz, tr);
-            int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-            bool have = true;
+            const int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
+            bool left_first;
             if (MODE == 1) {
-                // push lc then rc: rc is visited first (DeviceBVH.cuh:154-166)
-                if (hl && hr) { trav_push(S, L.sp, lref, 0.0f); L.sp++; L.ref = rref; }
-                else if (hl) L.ref = lref;
-                else if (hr) L.ref = rref;
-                else have = false;
+                left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
             } else {
                 hl = hl && !(tl > L.bound);
                 hr = hr && !(tr > L.bound);
-                if (hl && hr) {
-                    bool left_first = tl <= tr;
-                    trav_push(S, L.sp, left_first ? rref : lref, left_first ? tr : tl);
-                    L.sp++;
-                    L.ref = left_first ? lref : rref;
-                } else if (hl) L.ref = lref;
-                else if (hr) L.ref = rref;
-                else have = false;
+                left_first = tl <= tr;
             }
-            if (STATS && (uint32_t)L.sp > ray_sp) ray_sp = (uint32_t)L.sp;
-            if (have) state = L.ref >= 0 ? TR_INNER : TR_LEAF;
-            else {
-                int r = trav_pop<MODE>(L, S);
-                if (r == 0) finished = true;
-                else state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
+            const bool both = hl && hr, any = hl || hr;
+            const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+            if (both) {
+                trav_push(S, L.sp, left_first ? rref : lref, left_first ? tr : tl);
+                L.sp++;
+                if (STATS && (uint32_t)L.sp > ray_sp) ray_sp = (uint32_t)L.sp;
             }
+            L.ref = any ? near_ref : L.ref;
+            state = any ? (near_ref >= 0 ? TR_INNER : TR_LEAF) : state;
+            need_pop = !any;
         }
+    }
+    if (need_pop) {
+        int r = trav_pop<MODE>(L, S);
+        finished = r == 0;
+        state = r == 1 ? (L.ref >= 0 ? TR_INNER : TR_LEAF) : TR_POP;
     }
     return finished;
 }
@@ -819,8 +837,11 @@ struct MParams {
     int32_t logic_min, leaf_min;
 };
 
+#ifndef CRT_MEGA_WAVES
+#define CRT_MEGA_WAVES 4
+#endif
 template <int MODE, bool STATS, bool LDS_TABLES>
-__global__ __launch_bounds__(256) void k_mega(const MParams M)
+__global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
 {
     extern __shared__ int2 s_lds2[];
     const LParams& P = M.P;
