@@ -17,7 +17,7 @@
 //              flags bit0 = has_emit, bit1 = SPECULAR
 //   ltri       4 x float4 per light triangle (shape order): (v1.xyz, v2.x) (v2.yz, v3.xy)
 //              (v3.z, n.xyz) (ke.xyz, area_of_obj)
-//   lights     uint2 (first, count) per light object
+//   lights     uint4 (first, count, division magic, shifts) per light object
 #ifndef CRT_DEVICE_H
 #define CRT_DEVICE_H
 
@@ -38,12 +38,37 @@ struct DevScene {
     const int32_t* tri_mat;
     const float4* mats;
     const float4* ltri;
-    const uint2* lights;
+    const uint4* lights;
     const int32_t* leaf_count; // only read for leaves with more than 15 triangles
     int32_t root_fast;   // root of the SAH tree over the reference leaves (crt_accel.h)
     int32_t root_exact;  // root of the reference-topology tree
     int32_t n_lights;
 };
+
+// Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less
+// divide sequence (Granlund & Montgomery / Hacker's Delight 10-9): q = (t + ((n - t) >> sh1)) >> sh2,
+// t = mulhi(m, n).  Valid for every n and every d >= 1 (tests/test_host_layer.py checks the host maths).
+struct FastDiv {
+    uint32_t m, sh; // sh = sh1 | sh2 << 8
+};
+inline FastDiv make_fastdiv(uint32_t d)
+{
+    uint32_t l = 0;
+    while (l < 32 && (1ull << l) < d) l++;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh = (l < 1 ? l : 1u) | ((l > 0 ? l - 1 : 0u) << 8);
+    return f;
+}
+__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t m, uint32_t sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t t = __umulhi(m, n);
+#else
+    uint32_t t = (uint32_t)(((unsigned long long)m * n) >> 32);
+#endif
+    return (t + ((n - t) >> (sh & 255u))) >> (sh >> 8);
+}
 
 struct F3 {
     float x, y, z;

@@ -49,7 +49,7 @@ namespace {
 // Statistics counters are sharded over CNT_SHARDS cache lines (16 x u64 each): thousands of
 // atomics per launch on ONE address serialise at the memory side (~12 ns each) and cost more
 // than the kernel itself.  The host sums the shards.
-enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_COUNT };
+enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_CYC_LOGIC, C_CYC_LEAF, C_CYC_INNER, C_CYC_OTHER, C_COUNT };
 #define CNT_SHARDS 256
 #define CNT_STRIDE 16
 // The work-item cursor is sharded too: shard s hands out items [s*per, (s+1)*per); a wave
@@ -92,6 +92,7 @@ struct LParams {
     uint32_t n_items;       // nslots * samples in this chunk
     uint32_t items_per_shard;
     uint32_t n_mats;
+    FastDiv lsn_div, nslots_div, tiles_x_div;
     unsigned int* item_next; // [ITEM_SHARDS * ITEM_STRIDE] cursors, relative to the shard start
     float4* L;              // per work item radiance
     unsigned long long* counters;
@@ -110,13 +111,13 @@ struct TParams {
 };
 
 // work item slot -> pixel.  false for padding slots (ragged image edge / tile beyond the image).
-__device__ __forceinline__ bool slot_to_pixel(uint32_t slot, uint32_t rank, uint32_t world, uint32_t n_tiles, uint32_t tiles_x,
+__device__ __forceinline__ bool slot_to_pixel(uint32_t slot, uint32_t rank, uint32_t world, uint32_t n_tiles, uint32_t tiles_x, FastDiv tiles_x_div,
                                               uint32_t width, uint32_t height, uint32_t& i, uint32_t& j)
 {
     uint32_t tile = (slot >> 6) * world + rank;
     uint32_t pix = slot & 63u;
     if (tile >= n_tiles) return false;
-    uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    uint32_t ty = fast_div(tile, tiles_x_div.m, tiles_x_div.sh), tx = tile - ty * tiles_x;
     i = tx * CRT_TILE + (pix & 7u);
     j = ty * CRT_TILE + (pix >> 3);
     return i < width && j < height;
@@ -164,10 +165,10 @@ struct Lane {
 __device__ __forceinline__ void decode_item(const LParams& P, uint32_t item, uint32_t& pixel_index, uint32_t& k, bool& valid,
                                             uint32_t& pi, uint32_t& pj)
 {
-    uint32_t s = item / P.nslots;
+    uint32_t s = fast_div(item, P.nslots_div.m, P.nslots_div.sh);
     uint32_t slot = item - s * P.nslots;
     k = P.sample_begin + s;
-    valid = slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.width, P.height, pi, pj);
+    valid = slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.tiles_x_div, P.width, P.height, pi, pj);
     pixel_index = pj * P.width + pi; // Render.cuh:336
 }
 
@@ -176,7 +177,7 @@ __device__ __forceinline__ void decode_item(const LParams& P, uint32_t item, uin
 // Materials and lights are tiny tables read by every lane: LDS copies when they fit.
 template <bool LDS_TABLES> struct Tables {
     const float4* mats;
-    const uint2* lights;
+    const uint4* lights;
 };
 template <bool LDS_TABLES>
 __device__ __forceinline__ float4 mat_row(const Tables<LDS_TABLES>& tb, uint32_t mat, int row) { return tb.mats[mat * 3 + row]; }
@@ -187,10 +188,11 @@ template <bool LDS_TABLES>
 __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_TABLES>& tb, Lane& s, F3 f_r)
 {
     const DevScene& sc = P.sc;
-    uint32_t li = s.q / (uint32_t)P.lsn, sj = s.q - li * (uint32_t)P.lsn;
-    uint2 lg = tb.lights[li];
-    U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, li * (uint32_t)P.lsn + sj);
-    uint32_t ti = rl.x % lg.y; // DeviceLights.cuh:35
+    // sample q = light li, repetition sj; the draw index li * lsn + sj is q itself
+    const uint32_t li = fast_div(s.q, P.lsn_div.m, P.lsn_div.sh);
+    const uint4 lg = tb.lights[li];
+    U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, s.q);
+    const uint32_t ti = rl.x - fast_div(rl.x, lg.z, lg.w) * lg.y; // rand % triangle count (DeviceLights.cuh:35)
     const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
     float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3];
     float alpha = rng_uniform(rl.y); // DeviceTriangle.cuh:69-71
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     __shared__ uint32_t s_cnt[5];
     __shared__ float4 s_mats[LDS_TABLES ? LOGIC_TABLE_MAX * 3 : 1];
-    __shared__ uint2 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
+    __shared__ uint4 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
     Tables<LDS_TABLES> tb;
     if (LDS_TABLES) {
         if (threadIdx.x < (uint32_t)P.n_mats * 3u) s_mats[threadIdx.x] = sc.mats[threadIdx.x];
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
     const uint32_t slot = blockIdx.x * 256u + tid;
     __shared__ uint32_t s_cnt[5];
     __shared__ float4 s_mats[LDS_TABLES ? LOGIC_TABLE_MAX * 3 : 1];
-    __shared__ uint2 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
+    __shared__ uint4 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
     Tables<LDS_TABLES> tb;
     if (LDS_TABLES) {
         if (threadIdx.x < (uint32_t)P.n_mats * 3u) s_mats[threadIdx.x] = sc.mats[threadIdx.x];
@@ -883,6 +885,14 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
     L.any_hit = false; L.nx = L.ny = L.nz = false;
     L.r.o = L.r.d = L.r.inv = f3(0.0f, 0.0f, 0.0f);
 
+#ifdef CRT_STAMPS
+    // diagnostic build only: shader-clock cycles this wave spends in each section (never used by any output)
+    unsigned long long cyc_logic = 0, cyc_leaf = 0, cyc_inner = 0, cyc_other = 0;
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define CRT_STAMP(acc) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc += t_now - t_prev; t_prev = t_now; }
+#else
+#define CRT_STAMP(acc)
+#endif
     for (;;) {
         // ---- path logic for parked lanes, batched ----
         const unsigned long long parked = __ballot(state == TR_IDLE && !dead);
@@ -923,10 +933,16 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
                     dead = true;
                 }
             }
+            CRT_STAMP(cyc_logic)
             continue; // re-evaluate: lanes answered without traversal are parked again
         }
+        CRT_STAMP(cyc_other)
         // ---- one traversal step for the lanes in flight ----
         bool nothing_to_do = false;
+#ifdef CRT_STAMPS
+        const bool leaf_phase_stamp = __popcll(__ballot(state == TR_LEAF)) > 0 &&
+                                      (__popcll(__ballot(state == TR_LEAF)) >= M.leaf_min || __popcll(__ballot(state == TR_INNER)) == 0);
+#endif
         const bool finished = trav_step<MODE, STATS>(sc, L, state, S, M.leaf_min, tc, ray_sp, nothing_to_do);
         if (finished) {
             if (STATS) {
@@ -937,7 +953,17 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
             }
             state = TR_IDLE;
         }
+#ifdef CRT_STAMPS
+        if (leaf_phase_stamp) { CRT_STAMP(cyc_leaf) } else { CRT_STAMP(cyc_inner) }
+#endif
     }
+#ifdef CRT_STAMPS
+    if (lane == 0) {
+        unsigned long long* cs2 = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+        atomicAdd(&cs2[C_CYC_LOGIC], cyc_logic); atomicAdd(&cs2[C_CYC_LEAF], cyc_leaf);
+        atomicAdd(&cs2[C_CYC_INNER], cyc_inner); atomicAdd(&cs2[C_CYC_OTHER], cyc_other);
+    }
+#endif
 
     // ---- counters ----
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
@@ -994,12 +1020,22 @@ __device__ __forceinline__ uint8_t tonemap(float c)
     return to_u8(255 * det_powf(cl, 0.6f));
 }
 
+__device__ __forceinline__ FastDiv make_fastdiv_dev(uint32_t d)
+{
+    // k_accumulate runs once per pixel: derive the magic on the fly (same formula as make_fastdiv)
+    uint32_t l = d > 1 ? 32u - (uint32_t)__clz((int)(d - 1)) : 0u;
+    FastDiv f;
+    f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh = (l < 1 ? l : 1u) | ((l > 0 ? l - 1 : 0u) << 8);
+    return f;
+}
+
 __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
 {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot >= A.nslots) return;
     uint32_t i = 0, j = 0;
-    bool valid = slot_to_pixel(slot, A.rank, A.world, A.n_tiles, A.tiles_x, A.width, A.height, i, j);
+    bool valid = slot_to_pixel(slot, A.rank, A.world, A.n_tiles, A.tiles_x, make_fastdiv_dev(A.tiles_x), A.width, A.height, i, j);
     F3 c = f3(0.0f, 0.0f, 0.0f);
     if (valid) {
         if (!A.first_chunk) c = f3(A.accum[slot], A.accum[A.nslots + slot], A.accum[2ull * A.nslots + slot]);
@@ -1113,7 +1149,7 @@ struct crt_scene {
     int device = 0;
     DevBuf<float4> nodes, tri_geo, mats, ltri;
     DevBuf<int32_t> tri_mat, leaf_count;
-    DevBuf<uint2> lights;
+    DevBuf<uint4> lights;
     // path pool + per-item radiance + cross-chunk accumulator
     DevBuf<float4> p_ro, p_rd, p_vx, p_la, p_cc, p_vn, p_rec_a, p_rec_b, L;
     DevBuf<uint4> p_id;
@@ -1424,6 +1460,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
             P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
             P.nslots = sh.nslots;
+            P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
             P.L = sc->L.p; P.counters = sc->counters.p; P.item_next = sc->item_next.p; P.n_mats = sc->n_mats;
             M.sc = sc->dev; M.counters = sc->counters.p; M.spill = sc->spill[0].p; M.spill_stride = lanes; M.stack_cap = lds_cap;
             M.logic_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LOGIC_MIN", 32));
@@ -1475,6 +1512,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 for (int sh2 = 0; sh2 < CNT_SHARDS; sh2++) stats->stack_max = std::max<uint64_t>(stats->stack_max, sc->h_counters[sh2 * CNT_STRIDE + C_MAXSP]);
                 float total = 0.0f;
                 HIP_CHECK(hipEventElapsedTime(&total, e0, e3));
+                stats->phase_cycles[0] = counter_sum(C_CYC_LOGIC); stats->phase_cycles[1] = counter_sum(C_CYC_LEAF);
+                stats->phase_cycles[2] = counter_sum(C_CYC_INNER); stats->phase_cycles[3] = counter_sum(C_CYC_OTHER);
                 stats->kernel_ms = (float)kernel_ms;
                 stats->logic_ms = 0.0f;
                 stats->total_ms = total;
@@ -1514,6 +1553,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
         P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
         P.nslots = sh.nslots;
+        P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
         P.L = sc->L.p;
         P.counters = sc->counters.p;
         P.item_next = sc->item_next.p;
@@ -1697,8 +1737,11 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             ltri[i * 4ull + 2] = make_float4(t.v3[2], t.normal[0], t.normal[1], t.normal[2]);
             ltri[i * 4ull + 3] = make_float4(m.ke[0], m.ke[1], m.ke[2], t.area_of_obj);
         }
-        std::vector<uint2> lights(d->n_lights);
-        for (uint32_t i = 0; i < d->n_lights; i++) lights[i] = make_uint2(d->lights[i].first_tri, d->lights[i].count);
+        std::vector<uint4> lights(d->n_lights);
+        for (uint32_t i = 0; i < d->n_lights; i++) {
+            FastDiv fd = make_fastdiv(d->lights[i].count);
+            lights[i] = make_uint4(d->lights[i].first_tri, d->lights[i].count, fd.m, fd.sh);
+        }
         sc->nodes.upload(nodes); sc->tri_geo.upload(geo); sc->tri_mat.upload(tri_mat); sc->mats.upload(mats);
         sc->ltri.upload(ltri); sc->lights.upload(lights); sc->leaf_count.upload(leaf_count);
         sc->counters.alloc((size_t)CNT_SHARDS * CNT_STRIDE);
