@@ -1000,7 +1000,8 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
 // picks a phase and gathers up to 64 rays that are IN that phase with a ballot + prefix rank
 // (mbcnt), so the phase bodies run with (nearly) all lanes active.  A workgroup is one wave: the
 // pool needs no inter-wave synchronisation at all.
-//   LDS per wave: 4 x 16 B ray vectors + POOL_LV x 8 B stack entries per ray.  The phase of ray r is kept
+//   LDS per wave: 3 x 16 B ray vectors + POOL_LV x 8 B stack entries per ray (1/direction and the pruning
+//   bound are recomputed every step: the kernel is latency bound, occupancy is worth more than ~40 VALU).  The phase of ray r is kept
 //   in a register of its "owner" lane (r mod 64); batches are formed and phase changes are sent back
 //   with ds_permute (lane-to-lane scatter through the LDS crossbar, no memory round trip).
 #ifndef POOL_P
@@ -1018,7 +1019,6 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
 struct PoolLds {
     float4 r0[POOL_P];          // origin.xyz, t_limit
     float4 r1[POOL_P];          // direction.xyz, best_t
-    float4 r2[POOL_P];          // 1/direction.xyz, pruning bound
     int4 r3[POOL_P];            // best_tri, best_leaf, sp | any_hit << 16, current node ref
     int2 stk[POOL_LV][POOL_P];  // traversal stack (node ref, t_enter); deeper levels spill to global memory
 };
@@ -1130,21 +1130,23 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
                     const int ts = trav_begin<MODE>(sc, L, s.kind, s.tl);
                     S.r0[id] = make_float4(L.r.o.x, L.r.o.y, L.r.o.z, L.t_limit);
                     S.r1[id] = make_float4(L.r.d.x, L.r.d.y, L.r.d.z, L.best_t);
-                    S.r2[id] = make_float4(L.r.inv.x, L.r.inv.y, L.r.inv.z, L.bound);
                     S.r3[id] = make_int4(L.best_tri, L.best_leaf, L.any_hit ? 0x10000 : 0, L.ref);
                     nph = ts == TR_IDLE ? PH_LOGIC : (ts == TR_INNER ? PH_INNER : PH_LEAF);
                 }
             }
         } else if (on) {
             // ---- traversal step for the gathered rays ----
-            const float4 q0 = S.r0[id], q1 = S.r1[id], q2 = S.r2[id];
+            const float4 q0 = S.r0[id], q1 = S.r1[id];
             int4 q3 = S.r3[id];
             RayT r;
-            r.o = f3(q0.x, q0.y, q0.z); r.d = f3(q1.x, q1.y, q1.z); r.inv = f3(q2.x, q2.y, q2.z);
+            r.o = f3(q0.x, q0.y, q0.z); r.d = f3(q1.x, q1.y, q1.z);
+            r.inv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z); // Ray.cuh:14 (same bits as trav_begin computed)
             const float t_limit = q0.w;
-            float best_t = q1.w, bound = q2.w;
+            float best_t = q1.w;
             int sp = q3.z & 0xffff;
             const bool any_hit = (q3.z & 0x10000) != 0;
+            // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
+            float bound = any_hit ? prune_bound(t_limit) : (MODE == 0 && q3.x >= 0 ? prune_bound(best_t) : FLT_MAX);
             int ref = q3.w;
             bool done = false, need_pop = false;
             if (act == PH_LEAF) {
@@ -1183,7 +1185,6 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
                     }
                 }
                 S.r1[id].w = best_t;
-                S.r2[id].w = bound;
                 need_pop = !done;
             } else {
                 if (STATS) tc.inner++;
@@ -1684,7 +1685,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        if (env_u32("CRT_PIPELINE", 1) == 1 || env_u32("CRT_PIPELINE", 1) == 3) {
+        if (env_u32("CRT_PIPELINE", 3) == 1 || env_u32("CRT_PIPELINE", 3) == 3) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
             const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
@@ -1704,7 +1705,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 }
 #undef CRT_MEGA_CASE
             };
-            const bool regroup = env_u32("CRT_PIPELINE", 1) == 3;
+            const bool regroup = env_u32("CRT_PIPELINE", 3) == 3;
             MParams M;
             std::memset(&M, 0, sizeof(M));
             int per_cu = 1;
