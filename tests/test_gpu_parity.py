@@ -224,3 +224,111 @@ def test_errors_are_reported_not_printed(renders):
     assert capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), None, None) == -1
     with pytest.raises(crt.CrtError):
         crt.Render(util.host_scene("cornell-box"), device=99)
+
+
+# ----------------------------------------------------------------------------------------------
+# Edge cases the reference's data model allows: other leaf sizes (bvh_thresh_n), no / several NEE
+# samples, paths that run into the 64-vertex bounce cap, one-leaf trees, every pipeline variant.
+# ----------------------------------------------------------------------------------------------
+def _write_box_scene(d, n_side=6, specular=False):
+    """A small closed room with an emissive quad and a tessellated floor (2 * n_side^2 + 12 triangles)."""
+    import os
+    v, f = [], []
+
+    def quad(a, b, c, e, mtl):
+        i = len(v)
+        v.extend([a, b, c, e])
+        f.append((mtl, i + 1, i + 2, i + 3))
+        f.append((mtl, i + 1, i + 3, i + 4))
+    S = 10.0
+    step = S / n_side
+    for i in range(n_side):
+        for j in range(n_side):
+            x0, z0 = i * step, j * step
+            quad((x0, 0, z0), (x0, 0, z0 + step), (x0 + step, 0, z0 + step), (x0 + step, 0, z0), "floor")
+    quad((0, S, 0), (S, S, 0), (S, S, S), (0, S, S), "wall")             # ceiling (faces down)
+    quad((0, 0, S), (0, S, S), (S, S, S), (S, 0, S), "wall")             # back wall, faces -z
+    quad((0, 0, 0), (S, 0, 0), (S, S, 0), (0, S, 0), "wall")             # front wall behind the camera, faces +z
+    quad((0, 0, 0), (0, S, 0), (0, S, S), (0, 0, S), "wall")             # x = 0, faces +x
+    quad((S, 0, 0), (S, 0, S), (S, S, S), (S, S, 0), "plate" if specular else "wall")  # x = S, faces -x
+    quad((4, S - 0.01, 4), (6, S - 0.01, 4), (6, S - 0.01, 6), (4, S - 0.01, 6), "light")
+    with open(os.path.join(d, "room.mtl"), "w") as m:
+        m.write("newmtl floor\nKd 0.7 0.6 0.5\nNs 1\nnewmtl wall\nKd 0.5 0.5 0.7\nNs 1\n"
+                "newmtl plate\nKd 0.1 0.2 0.3\nNs 500\nnewmtl light\nKe 30 25 20\nKd 0 0 0\nNs 1\n")
+    with open(os.path.join(d, "room.obj"), "w") as o:
+        o.write("mtllib room.mtl\n")
+        for p in v:
+            o.write("v %g %g %g\nvn 0 1 0\nvt 0 0\n" % p)
+        cur = None
+        for mtl, a, b, c in f:
+            if mtl != cur:
+                o.write("usemtl %s\n" % mtl)
+                cur = mtl
+            o.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, b, b, b, c, c, c))
+    return os.path.join(d, "room.obj"), d
+
+
+def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, seed=3):
+    obj, mtl = _write_box_scene(str(tmp_path), specular=specular)
+    scene = crt.Scene(w, h)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(thresh)
+    osc = O.OracleScene([(obj, mtl)], thresh)
+    assert scene.nodes().tobytes() == osc.nodes().tobytes()
+    eye = np.array([5.0, 5.0, 0.5], dtype=np.float32)
+    iv = crt.get_inverse_view_matrix(eye, [5.0, 4.0, 9.0], [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(70.0)
+    r = crt.Render(scene, spp, p_rr, lsn)
+    r.seed = seed
+    orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, p_rr, lsn, seed=seed)
+    try:
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (thresh, lsn, p_rr, mode)
+            assert np.array_equal(rgb, orgb)
+            assert r.stats["rays"] == st["rays"] and r.stats["probe_rays"] == st["probe_rays"]
+    finally:
+        r.free()
+    return st
+
+
+@pytest.mark.parametrize("thresh", [1, 2, 3, 5, 20, 200])
+def test_other_leaf_sizes(tmp_path, thresh):
+    """bvh_thresh_n other than 2: leaves with 1, 3..5, more than 15 triangles, and a tree that is one leaf."""
+    st = _compare_room(tmp_path, thresh, lsn=1, p_rr=0.6, spp=3)
+    assert st["rays"] > 5000
+
+
+@pytest.mark.parametrize("lsn", [0, 1, 3])
+def test_light_sample_counts(tmp_path, lsn):
+    st = _compare_room(tmp_path, 2, lsn=lsn, p_rr=0.6, spp=3)
+    assert (st["shadow_rays"] == 0) == (lsn == 0)
+
+
+def test_paths_hit_the_bounce_stack_cap(tmp_path):
+    """P_RR = 1 never terminates a path by roulette: closed room -> every path runs to the 64-vertex cap
+    (DeviceStack overflow semantics, Render.cuh:210) unless it finds the light first."""
+    st = _compare_room(tmp_path, 2, lsn=1, p_rr=1.0, spp=1, w=24, h=18)
+    assert st["max_depth"] == 63
+
+
+def test_specular_probe_rays(tmp_path):
+    st = _compare_room(tmp_path, 2, lsn=2, p_rr=0.8, spp=4, specular=True)
+    assert st["probe_rays"] > 0
+
+
+@pytest.mark.parametrize("pipeline", ["1", "2", "3"])
+def test_all_pipeline_variants_agree(renders, pipeline, monkeypatch):
+    """CRT_PIPELINE selects k_mega2 (3, default), the one-ray-per-lane megakernel (1) or the wavefront rounds (2)."""
+    monkeypatch.setenv("CRT_PIPELINE", pipeline)
+    for name in ("cornell-box", "veach-mis"):
+        t = util.task(name)
+        eye, iv, fov = util.camera(name)
+        r = renders[name]
+        r.traversal = crt.TRAVERSAL_FAST
+        r.set_spp(2)
+        rgb = r.run_view(eye, iv, fov, width=128, height=96)
+        orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 128, 96, 2, t.P_RR, t.light_sample_n)
+        assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
+        assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
