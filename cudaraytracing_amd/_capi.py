@@ -61,7 +61,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("probe_rays", C.c_uint64),
                 ("inner_pops", C.c_uint64), ("leaf_pops", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
-                ("stack_sum", C.c_uint64), ("stack_max", C.c_uint64), ("phase_cycles", C.c_uint64 * 4),
+                ("stack_sum", C.c_uint64), ("stack_max", C.c_uint64), ("phase_cycles", C.c_uint64 * 24),
                 ("kernel_ms", C.c_float), ("logic_ms", C.c_float), ("total_ms", C.c_float),
                 ("kernel_launches", C.c_uint32)]
 

@@ -46,12 +46,13 @@ extern "C" void crt_set_last_error_(const char* msg);
 
 namespace {
 
-// Statistics counters are sharded over CNT_SHARDS cache lines (16 x u64 each): thousands of
+// Statistics counters are sharded over CNT_SHARDS cache lines (CNT_STRIDE x u64 each): thousands of
 // atomics per launch on ONE address serialise at the memory side (~12 ns each) and cost more
 // than the kernel itself.  The host sums the shards.
-enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_CYC_LOGIC, C_CYC_LEAF, C_CYC_INNER, C_CYC_OTHER, C_COUNT };
+enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_CYC_LOGIC, C_CYC_LEAF, C_CYC_INNER, C_CYC_OTHER,
+       C_DIAG /* CRT_DIAG_N more diagnostic slots (-DCRT_STAMPS builds) */, C_COUNT = C_DIAG + 20 };
 #define CNT_SHARDS 256
-#define CNT_STRIDE 16
+#define CNT_STRIDE 40
 // The work-item cursor is sharded too: shard s hands out items [s*per, (s+1)*per); a wave
 // starts at its home shard and moves on when a shard is exhausted.
 #define ITEM_SHARDS 64
@@ -153,7 +154,16 @@ __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, un
 // ---------------------------------------------------------------- logic ----
 struct PathCounters {
     uint32_t rays, shadow, probe, paths;
+#ifdef CRT_STAMPS
+    uint32_t sec[8]; // diagnostic build: wave passes through each logic section and lanes that needed it
+    uint32_t sec_lanes[8];
+#endif
 };
+#ifdef CRT_STAMPS
+#define CRT_SEC(i, cond) { const unsigned long long m_ = __ballot(cond); if (m_) { cnt.sec[i]++; cnt.sec_lanes[i] += (uint32_t)__popcll(m_); } }
+#else
+#define CRT_SEC(i, cond)
+#endif
 
 struct Lane {
     F3 ro, rd, pos, Ld, c, nrm;
@@ -264,6 +274,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
     int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
 
+    CRT_SEC(0, stage == ST_SHADOW) CRT_SEC(1, stage == ST_HIT) CRT_SEC(2, stage == ST_PROBE)
     // ---- phase 1: consume the result of the slot's last ray ----
     if (stage == ST_SHADOW) {
         // visibility of next-event sample q (Render.cuh:19-27, :272-284)
@@ -342,6 +353,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
 
     // ---- phase 2: a new vertex (pos, vtri) at `depth`, reached along s.rd ----
     F3 f_r = f3(0.0f, 0.0f, 0.0f);
+    CRT_SEC(3, do_enter)
     if (do_enter) {
         float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
         s.nrm = f3(g.y, g.z, g.w);
@@ -364,6 +376,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
+    CRT_SEC(4, do_nee_done)
     if (do_nee_done) {
         pl.rec_a[(size_t)s.depth * pl.n + slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, 0.0f);
         bool stop = s.depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
@@ -389,6 +402,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 4: path complete ----
+    CRT_SEC(5, do_finish)
     if (do_finish) {
         F3 L = finish_path(P, tb, slot, fin_deepest, fin_emissive, fin_ke);
         P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -396,6 +410,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 5: take the next work item, camera ray (Render.cuh:344-347) ----
+    CRT_SEC(6, do_new)
     if (do_new) {
         s.stage = ST_DEAD;
         for (;;) {
@@ -424,6 +439,7 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 6: next-event sample q of the current vertex ----
+    CRT_SEC(7, do_shadow_setup)
     if (do_shadow_setup) {
         setup_shadow(P, tb, s, f_r);
         s.stage = ST_SHADOW;
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(256) void k_logic(const LParams P)
     __syncthreads();
 
     PathCounters cnt;
-    cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
+    cnt = PathCounters{};
     bool emitted = false;
     uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = in_range ? (st >> 8) & 15u : (uint32_t)ST_DEAD;
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
     S.cap = M.stack_cap;
 
     PathCounters cnt;
-    cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
+    cnt = PathCounters{};
     TravCounters tc;
     tc.inner = tc.leaf = tc.tests = tc.hits = 0;
     uint32_t max_sp = 0, sum_sp = 0, ray_sp = 0;
@@ -1036,11 +1052,20 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
     tb.mats = sc.mats; tb.lights = sc.lights;
 
     PathCounters cnt;
-    cnt.rays = cnt.shadow = cnt.probe = cnt.paths = 0;
+    cnt = PathCounters{};
     TravCounters tc;
     tc.inner = tc.leaf = tc.tests = tc.hits = 0;
     uint32_t max_sp = 0, sum_sp = 0;
 
+#ifdef CRT_STAMPS
+    // diagnostic build only: shader-clock cycles, iterations and gathered rays per phase (never used by any output)
+    unsigned long long dg_cyc[4] = {0, 0, 0, 0};
+    unsigned dg_iter[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};
+    unsigned long long dg_prev = __builtin_amdgcn_s_memtime();
+#define CRT_STAMP2(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_cyc[i] += t_now - dg_prev; dg_prev = t_now; }
+#else
+#define CRT_STAMP2(i)
+#endif
     uint32_t ph[POOL_Q]; // phase of the rays this lane owns: lane, lane + 64, ...
 #pragma unroll
     for (int q = 0; q < POOL_Q; q++) {
@@ -1063,6 +1088,7 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
             n_leaf += __popcll(__ballot(ph[q] == PH_LEAF));
         }
         if (n_logic + n_inner + n_leaf == 0) break; // every ray of the pool is dead
+        CRT_STAMP2(3)
         uint32_t act;
         if (n_logic >= M.logic_min || (n_inner == 0 && n_leaf == 0)) act = PH_LOGIC;
         else if (n_leaf >= M.leaf_min || n_inner == 0) act = PH_LEAF;
@@ -1091,6 +1117,9 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
         }
         const int n = min(taken, 64);
         const bool on = lane < n;
+#ifdef CRT_STAMPS
+        dg_iter[act]++; dg_lanes[act] += (unsigned)n;
+#endif
         const uint32_t id = on ? got - 1u : 0u;
         const uint32_t g = base + id;
         uint32_t nph = PH_DEAD; // new phase of the ray this lane processes
@@ -1237,7 +1266,21 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
             const uint32_t back = (uint32_t)__builtin_amdgcn_ds_bpermute((sent_to[q] >= 0 ? sent_to[q] : lane) << 2, (int)nph);
             if (sent_to[q] >= 0) ph[q] = back;
         }
+        CRT_STAMP2(act)
     }
+#ifdef CRT_STAMPS
+    if (lane == 0) {
+        unsigned long long* cs2 = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+        atomicAdd(&cs2[C_CYC_LOGIC], dg_cyc[PH_LOGIC]); atomicAdd(&cs2[C_CYC_LEAF], dg_cyc[PH_LEAF]);
+        atomicAdd(&cs2[C_CYC_INNER], dg_cyc[PH_INNER]); atomicAdd(&cs2[C_CYC_OTHER], dg_cyc[3]);
+        for (int i = 0; i < 3; i++) { atomicAdd(&cs2[C_DIAG + i], (unsigned long long)dg_iter[i]); atomicAdd(&cs2[C_DIAG + 3 + i], (unsigned long long)dg_lanes[i]); }
+        for (int i = 0; i < 8; i++) atomicAdd(&cs2[C_DIAG + 6 + i], (unsigned long long)cnt.sec[i]);
+    }
+    for (int i = 0; i < 6; i++) {
+        // lanes per logic section (sections 0..5; 6 and 7 follow from the rest)
+        if (lane == 0) atomicAdd(&M.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + C_DIAG + 14 + i], (unsigned long long)cnt.sec_lanes[i == 5 ? 7 : i]);
+    }
+#endif
 
     // ---- counters ----
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
@@ -1260,6 +1303,591 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
             atomicAdd(&cs[C_TESTS], (unsigned long long)c);
             atomicAdd(&cs[C_HITS], (unsigned long long)d);
             atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
+            atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
+        }
+    }
+}
+
+// --------------------------------------- megakernel, queued sub-phases ----
+// k_mega2 spends 22 % of its cycles in a logic phase whose sections each serve 20-60 % of the gathered
+// lanes, 11 % in the census / permute gather, and its inner-node batches average 47 of 64 lanes
+// (-DCRT_STAMPS counters).  k_mega3 keeps the wave-private LDS ray pool and changes three things:
+//   * regrouping by QUEUES: every phase owns a ring of ray ids in LDS; a batch is the 64 oldest ids of the
+//     chosen ring (one ds_read_u8), and a processed ray is appended to the ring of its new phase at
+//     count + prefix-popcount of the ballot (one ds_write_b8).  Counts and heads are wave-uniform scalars;
+//     the cost is independent of the pool size.
+//   * the path logic is three phases of its own, so that a gathered lane only runs what its path needs:
+//       LA  result of a shadow / closest / probe ray -> (enter the vertex) -> next next-event sample
+//       LB  last next-event sample consumed -> vertex record, Russian roulette, bounce ray
+//       LC  path ends (miss / emitter / roulette) -> backward recursion, next work item, camera ray
+//     the traversal step routes a finished ray from flag bits in its LDS record; a phase that finds the
+//     path belongs elsewhere (emitter found in LA, roulette stop in LB) parks it there without a ray.
+//   * rays whose origin, direction and 1/direction are all finite (all but a handful) test boxes with
+//     v_min / v_max / v_min3 / v_max3: for finite operands min(t_lo, t_hi) IS the reference's sign-selected
+//     entry distance (rounding is monotone), so the bits are the same; the others keep the reference
+//     formula with its NaN behaviour (DeviceBVH.cuh:97-121) and walk the reference topology.
+#define PH3_INNER 0
+#define PH3_LEAF 1
+#define PH3_LA 2
+#define PH3_LB 3
+#define PH3_LC 4
+#define PH3_N 5
+#define PH3_NONE 7
+#define ST_FIN 5   /* path complete, backward recursion pending (q bit 0: the deepest vertex is an emitter) */
+#define ST_NEED 6  /* vertex entered with zero next-event samples: straight to roulette */
+#define RF_ANYHIT 0x10000   /* traversal stops at the first accepted hit closer than the light */
+#define RF_SHADOW 0x20000   /* the ray is a next-event sample ... */
+#define RF_LAST 0x40000     /* ... and the last one of its vertex */
+#define RF_PROBE 0x80000    /* SPECULAR emitter probe */
+#define RF_EXACT 0x100000   /* reference box arithmetic (non-finite operands) */
+#ifndef POOL3_P
+#define POOL3_P 128
+#endif
+#define POOL3_QCAP 128      /* ring capacity: power of two >= POOL3_P, ids fit a byte */
+#if POOL3_P > POOL3_QCAP || POOL3_QCAP > 256
+#error "POOL3_QCAP must be a power of two in [POOL3_P, 256]"
+#endif
+
+struct Pool3Lds {
+    float4 r0[POOL3_P];          // origin.xyz, t_limit
+    float4 r1[POOL3_P];          // direction.xyz, best_t
+    int4 r3[POOL3_P];            // best_tri, best_leaf, sp | RF_* flags, current node ref
+    int2 stk[POOL_LV][POOL3_P];  // traversal stack (node ref, t_enter); deeper levels spill to global memory
+    uint8_t ring[PH3_N][POOL3_QCAP];
+};
+
+struct MParams3 {
+    MParams M;
+    int32_t thr[PH3_N]; // a phase runs as soon as this many rays wait for it (else the fullest one does)
+};
+
+struct NewRay {
+    F3 o, d;
+    float tl;
+    uint32_t kind, flags;
+};
+
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// hit_AABB (DeviceBVH.cuh:87-126) for operands that are all finite: same products, entry = per-axis minimum
+__device__ __forceinline__ bool slab_test_finite(float4 lo, float4 hi, F3 o, F3 inv, float& t_enter)
+{
+    const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
+    const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
+    const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+    t_enter = fmax3(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1), __builtin_fminf(z0, z1));
+    const float t_exit = fmin3(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1), __builtin_fmaxf(z0, z1));
+    return t_enter <= t_exit + CRT_EPSILON && t_exit >= 0;
+}
+
+// Where a ray goes once its traversal is over.
+__device__ __forceinline__ uint32_t route_done(uint32_t flags, int best_tri)
+{
+    if (flags & RF_SHADOW) return (flags & RF_LAST) ? PH3_LB : PH3_LA;
+    return ((flags & RF_PROBE) || best_tri >= 0) ? PH3_LA : PH3_LC;
+}
+
+// Writes the new ray into the pool record `id` and returns its first phase.
+template <int MODE>
+__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt)
+{
+    cnt.rays++;
+    cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
+    cnt.probe += (nr.flags & RF_PROBE) ? 1u : 0u;
+    const F3 inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z); // Ray.cuh:14
+    uint32_t flags = nr.flags;
+    const bool finite = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX &&
+                        absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX; // a finite 1/d has a finite d
+    if (MODE == 1 || !finite) flags |= RF_EXACT;
+    // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
+    // topology, whose box tests are the reference's own (crt_accel.h)
+    const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX;
+    const int ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
+    bool answered = false;
+    if (MODE == 0 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
+        flags |= RF_ANYHIT;
+        // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
+        answered = !(nr.tl == nr.tl) || nr.tl == -pinf();
+    }
+    S.r0[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.tl);
+    S.r1[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, FLT_MAX);
+    S.r3[id] = make_int4(-1, -1, (int)flags, ref);
+    if (answered) return route_done(flags, -1);
+    return ref >= 0 ? PH3_INNER : PH3_LEAF;
+}
+
+// LA: consumes the result of a next-event sample that is not the last one of its vertex, of a closest-hit ray
+// that found a surface, or of a probe ray; enters the vertex if it is new; sets up the next next-event sample.
+// Returns PH3_NONE when a ray was emitted into nr, else the phase the path has to visit instead.
+__device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 q0, const float4 q1, const int res_tri,
+                                            PathCounters& cnt, NewRay& nr)
+{
+    const DevScene& sc = P.sc;
+    const Pool& pl = P.pool;
+    const float4 la = pl.la[g];
+    const uint4 idv = pl.id[g];
+    const float4 vn = pl.vn[g];
+    const uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = (st >> 8) & 15u;
+    const float res_t = q1.w;
+    Lane s;
+    s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
+    s.Ld = f3(la.x, la.y, la.z);
+    s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
+    s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
+    s.ro = f3(q0.x, q0.y, q0.z); s.tl = q0.w;
+    s.rd = f3(q1.x, q1.y, q1.z);
+    s.pos = s.ro; s.vtri = 0; s.c = f3(0.0f, 0.0f, 0.0f); s.kind = RAY_NONE;
+    bool do_enter = false, do_setup = false;
+    if (stage == ST_SHADOW) {
+        // visibility of next-event sample q (Render.cuh:19-27, :272-284); shadow rays start at the vertex
+        const float4 cc = pl.cc[g];
+        if (!(s.tl - res_t > CRT_EPSILON)) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
+        s.q++;
+        do_setup = true;
+    } else if (stage == ST_HIT) {
+        // the camera / bounce ray found vertex `depth` (Render.cuh:207-213)
+        const F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
+        do_enter = true;
+        if (s.depth > 0) {
+            // the previous vertex (normal / material still in the vn plane) is not the deepest one: cosine of its indirect term (Render.cuh:291)
+            const size_t pr = (size_t)(s.depth - 1) * pl.n + g;
+            const F3 pn = s.nrm;
+            float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
+            cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
+            pl.rec_a[pr].w = cos_prev;
+            const float4 pm1 = mat_row(tb, s.mat, 1);
+            if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
+                const float ns = mat_row(tb, s.mat, 0).w;
+                const float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
+                const float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
+                const F3 in = unit3(f3(pb.x, pb.y, pb.z));
+                const F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
+                const float d_theta = (float)((double)(delta_coeff * 30) * 3.14159265358979323846 / 180);
+                const float d_phi = (float)((double)(delta_coeff * 120) * 3.14159265358979323846 / 180);
+                const U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
+                const F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
+                // the probe leaves from prev.pos (= this ray's origin); the bounce direction waits in rec_b[depth]
+                pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f);
+                pl.vx[g] = make_float4(pos.x, pos.y, pos.z, __int_as_float(res_tri));
+                pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_PROBE << 8) | (s.q << 16)));
+                nr.o = s.ro; nr.d = unit3(refd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = RF_PROBE;
+                return PH3_NONE;
+            }
+        }
+        s.pos = pos; s.vtri = (uint32_t)res_tri;
+    } else { // ST_PROBE: the probe ray of vertex depth-1 (Render.cuh:304-313); vn still describes that vertex
+        const float4 vx = pl.vx[g];
+        s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
+        if (res_tri >= 0) {
+            const int hmat = sc.tri_mat[res_tri];
+            const float4 h1 = mat_row(tb, hmat, 1);
+            if (__float_as_uint(h1.w) & 1u) {
+                const float4 h2 = mat_row(tb, hmat, 2);
+                const size_t pr = (size_t)(s.depth - 1) * pl.n + g;
+                const F3 pn = s.nrm;
+                const float4 pm0 = mat_row(tb, s.mat, 0), pm1 = mat_row(tb, s.mat, 1);
+                const float log_shininess = det_log10f(pm0.w);
+                const float shininess_coeff = (float)((double)log_shininess * 0.5 + 1);
+                const float ip = (float)(2.0f * 3.14159265358979323846) / 8.f;
+                const F3 hp = add3(s.ro, scalel3(res_t, s.rd));
+                float ct = dot3(unit3(sub3(hp, s.ro)), pn); // probe origin == prev.pos
+                ct = ct > 0.0f ? ct : 0.0f;
+                // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
+                const F3 kekd = mul3(f3(h2.x, h2.y, h2.z), f3(pm1.x, pm1.y, pm1.z));
+                const F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
+                float4 a = pl.rec_a[pr];
+                a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
+                pl.rec_a[pr] = a;
+            }
+        }
+        const float4 pb = pl.rec_b[(size_t)s.depth * pl.n + g]; // the bounce direction that found the current vertex
+        s.rd = f3(pb.x, pb.y, pb.z);
+        do_enter = true;
+    }
+    if (do_enter) { // a new vertex (pos, vtri) at `depth`, reached along s.rd
+        const float4 gq = sc.tri_geo[(size_t)s.vtri * 3 + 2];
+        s.nrm = f3(gq.y, gq.z, gq.w);
+        s.mat = (uint32_t)sc.tri_mat[s.vtri];
+        pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
+        pl.vx[g] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
+        pl.vn[g] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
+        const float4 m1 = mat_row(tb, s.mat, 1);
+        if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+            pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16)));
+            return PH3_LC;
+        }
+        s.Ld = f3(0.0f, 0.0f, 0.0f);
+        s.q = 0;
+        if (sc.n_lights * P.lsn > 0) do_setup = true;
+        else {
+            pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
+            return PH3_LB;
+        }
+    } // (after a next-event sample the vertex is the origin of the shadow ray: s.pos == s.ro already)
+    // next-event sample q of the current vertex
+    const float4 m0 = mat_row(tb, s.mat, 0);
+    setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
+    pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
+    pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+    nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
+    nr.flags = RF_SHADOW | (s.q + 1 == (uint32_t)(sc.n_lights * P.lsn) ? RF_LAST : 0u);
+    (void)do_setup; (void)cnt;
+    return PH3_NONE;
+}
+
+// LB: direct light of vertex `depth` is complete -> vertex record, Russian roulette, bounce (Render.cuh:210-228).
+__device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 q0, const float4 q1, PathCounters& cnt, NewRay& nr)
+{
+    const Pool& pl = P.pool;
+    const float4 la = pl.la[g];
+    const uint4 idv = pl.id[g];
+    const uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = (st >> 8) & 15u;
+    uint32_t depth = st & 255u;
+    F3 Ld = f3(la.x, la.y, la.z);
+    if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
+        const float4 cc = pl.cc[g];
+        if (!(q0.w - q1.w > CRT_EPSILON)) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
+    }
+    pl.rec_a[(size_t)depth * pl.n + g] = make_float4(Ld.x, Ld.y, Ld.z, 0.0f);
+    bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
+    U4 rb;
+    rb.x = rb.y = rb.z = rb.w = 0;
+    if (!stop) {
+        rb = rng_draw(P.seed, idv.x, idv.y, depth, RNG_BOUNCE, 0);
+        stop = rng_uniform(rb.x) > P.p_rr;
+    }
+    if (stop) {
+        pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8)));
+        return PH3_LC;
+    }
+    const float4 vn = pl.vn[g], vx = pl.vx[g];
+    const F3 ndir = unit3(sample_hemisphere(f3(vn.x, vn.y, vn.z), rng_uniform(rb.y), rng_uniform(rb.z)));
+    depth++;
+    pl.la[g] = make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8)));
+    nr.o = f3(vx.x, vx.y, vx.z); nr.d = unit3(ndir); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
+    (void)cnt;
+    return PH3_NONE;
+}
+
+// LC: the path is complete (miss, emitter, roulette, stack full) -> backward recursion (Render.cuh:238-326), next
+// work item and its camera ray (Render.cuh:344-347).  Returns PH3_NONE with a ray in nr, or PH3_LC + dead = true.
+__device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr)
+{
+    const Pool& pl = P.pool;
+    const float4 la = pl.la[g];
+    const uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = (st >> 8) & 15u;
+    const uint32_t depth = st & 255u;
+    if (stage != ST_NEW) {
+        const uint4 idv = pl.id[g];
+        int deepest = (int)depth;
+        bool emissive = false;
+        F3 ke = f3(0.0f, 0.0f, 0.0f);
+        if (stage == ST_HIT) deepest = (int)depth - 1; // the ray that looked for vertex `depth` missed (Render.cuh:210)
+        else if ((st >> 16) & 1u) {
+            emissive = true;
+            const float4 m2 = mat_row(tb, __float_as_uint(pl.vn[g].w), 2);
+            ke = f3(m2.x, m2.y, m2.z);
+        }
+        const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
+        P.L[idv.z] = make_float4(L.x, L.y, L.z, 0.0f);
+    }
+    for (;;) {
+        const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
+        if (item == ITEM_NONE) return false;
+        bool valid; uint32_t pi, pj, pixel_index, k;
+        decode_item(P, item, pixel_index, k, valid, pi, pj);
+        if (!valid) continue; // padding slot of a ragged tile: take another item
+        cnt.paths++;
+        pl.id[g] = make_uint4(pixel_index, k, item, 0u);
+        const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
+        const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
+        const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
+        const F3 cd = unit3(f3(-x, y, 1));
+        const F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
+                         P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
+                         P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
+        pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8));
+        nr.o = f3(P.eye[0], P.eye[1], P.eye[2]); nr.d = unit3(wd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
+        return true;
+    }
+}
+
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mega3(const MParams3 M3)
+{
+    __shared__ Pool3Lds S;
+    const MParams& M = M3.M;
+    const LParams& P = M.P;
+    const DevScene& sc = M.sc;
+    const Pool& pl = P.pool;
+    const int lane = threadIdx.x;
+    const uint32_t base = blockIdx.x * (uint32_t)POOL3_P; // first global slot of this wave's pool
+    Tables<false> tb;
+    tb.mats = sc.mats; tb.lights = sc.lights;
+
+    PathCounters cnt;
+    cnt = PathCounters{};
+    TravCounters tc;
+    tc.inner = tc.leaf = tc.tests = tc.hits = 0;
+    uint32_t max_sp = 0;
+#ifdef CRT_STAMPS
+    unsigned long long dg_cyc[PH3_N + 1] = {0, 0, 0, 0, 0, 0};
+    unsigned dg_iter[PH3_N] = {0, 0, 0, 0, 0}, dg_lanes[PH3_N] = {0, 0, 0, 0, 0};
+    unsigned long long dg_prev = __builtin_amdgcn_s_memtime();
+#define CRT_STAMP3(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_cyc[i] += t_now - dg_prev; dg_prev = t_now; }
+#else
+#define CRT_STAMP3(i)
+#endif
+
+    // ring state: wave-uniform scalars
+    int qn[PH3_N], qh[PH3_N];
+#pragma unroll
+    for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; }
+    // every ray of the pool starts in LC with a path in stage NEW
+    {
+        const int n_valid = (int)min((uint32_t)POOL3_P, pl.n > base ? pl.n - base : 0u);
+        for (int i = lane; i < n_valid; i += 64) {
+            S.ring[PH3_LC][i] = (uint8_t)i;
+            pl.la[base + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_NEW << 8));
+        }
+        qn[PH3_LC] = n_valid;
+    }
+
+// appends the processed rays (lane active = `on`, ray `id`) to the ring of their new phase
+#define PUSH3()                                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < PH3_N; p++) {                                                                    \
+        const bool mine = on && nph == (uint32_t)p;                                                                        \
+        const unsigned long long m = __ballot(mine);                                                                       \
+        if (m) {                                                                                                           \
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
+            if (mine) S.ring[p][(qh[p] + qn[p] + rank) & (POOL3_QCAP - 1)] = (uint8_t)id;                                  \
+            qn[p] += (int)__popcll(m);                                                                                     \
+        }                                                                                                                  \
+    }
+// takes the (up to) 64 oldest rays of ring p
+#define POP3(p)                                                                                                            \
+    const int take = min(64, qn[p]);                                                                                       \
+    const bool on = lane < take;                                                                                           \
+    const uint32_t id = S.ring[p][(qh[p] + lane) & (POOL3_QCAP - 1)];                                                      \
+    qh[p] = (qh[p] + take) & (POOL3_QCAP - 1);                                                                             \
+    qn[p] -= take;                                                                                                         \
+    const uint32_t g = base + id;                                                                                          \
+    uint32_t nph = PH3_NONE;
+
+    for (;;) {
+        // ---- choose a phase: the first (logic first: it feeds the traversal) that has a full batch waiting, else the fullest ----
+        int act = -1;
+        if (qn[PH3_LC] >= M3.thr[PH3_LC]) act = PH3_LC;
+        else if (qn[PH3_LA] >= M3.thr[PH3_LA]) act = PH3_LA;
+        else if (qn[PH3_LB] >= M3.thr[PH3_LB]) act = PH3_LB;
+        else if (qn[PH3_LEAF] >= M3.thr[PH3_LEAF]) act = PH3_LEAF;
+        else if (qn[PH3_INNER] >= M3.thr[PH3_INNER]) act = PH3_INNER;
+        else {
+            int best = 0;
+#pragma unroll
+            for (int p = 0; p < PH3_N; p++)
+                if (qn[p] > best) { best = qn[p]; act = p; }
+            if (act < 0) break; // every ray of the pool is dead
+        }
+        CRT_STAMP3(PH3_N)
+#ifdef CRT_STAMPS
+        dg_iter[act]++;
+#endif
+        if (act == PH3_INNER || act == PH3_LEAF) {
+            // ---- traversal step ----
+            int take, qhead;
+            if (act == PH3_INNER) { take = min(64, qn[PH3_INNER]); qhead = qh[PH3_INNER]; qh[PH3_INNER] = (qhead + take) & (POOL3_QCAP - 1); qn[PH3_INNER] -= take; }
+            else { take = min(64, qn[PH3_LEAF]); qhead = qh[PH3_LEAF]; qh[PH3_LEAF] = (qhead + take) & (POOL3_QCAP - 1); qn[PH3_LEAF] -= take; }
+            const bool on = lane < take;
+            const uint32_t id = S.ring[act][(qhead + lane) & (POOL3_QCAP - 1)];
+            const uint32_t g = base + id;
+            uint32_t nph = PH3_NONE;
+#ifdef CRT_STAMPS
+            dg_lanes[act] += (unsigned)take;
+#endif
+            if (on) {
+                const float4 q0 = S.r0[id], q1 = S.r1[id];
+                int4 q3 = S.r3[id];
+                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q1.x, q1.y, q1.z);
+                const float t_limit = q0.w;
+                float best_t = q1.w;
+                const uint32_t flags = (uint32_t)q3.z & 0xffff0000u;
+                int sp = q3.z & 0xffff;
+                const bool any_hit = (flags & RF_ANYHIT) != 0;
+                // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
+                float bound = any_hit ? prune_bound(t_limit) : (MODE == 0 && q3.x >= 0 ? prune_bound(best_t) : FLT_MAX);
+                int ref = q3.w;
+                bool done = false, need_pop = false;
+                if (act == PH3_LEAF) {
+                    RayT r;
+                    r.o = o; r.d = d; r.inv = f3(0.0f, 0.0f, 0.0f); // tri_test reads o and d only
+                    const uint32_t code = (uint32_t)~ref;
+                    const int it = (int)(code >> 4);
+                    int nt = (int)(code & 15u);
+                    if (nt == 0) nt = sc.leaf_count[it];
+                    const bool two = nt > 1;
+                    float t0, t1;
+                    const bool a0 = tri_test(sc, it, r, t0);
+                    const bool a1 = tri_test(sc, two ? it + 1 : it, r, t1) && two;
+                    if (STATS) { tc.leaf++; tc.tests += two ? 2u : 1u; }
+                    if (any_hit) {
+                        const bool b0 = a0 && (t_limit - t0 > CRT_EPSILON);
+                        const bool b1 = a1 && (t_limit - t1 > CRT_EPSILON);
+                        done = b0 || b1;
+                        best_t = b0 ? t0 : (b1 ? t1 : best_t);
+                        q3.x = b0 ? it : (b1 ? it + 1 : q3.x);
+                    } else {
+                        // ascending index, strict <: the first of equal t inside a leaf wins (DeviceBVH.cuh:34-41); across leaves the
+                        // larger leaf start wins (reference visit order, see crt_trace.h)
+                        const bool w0 = a0 && (t0 < best_t || (t0 == best_t && it > q3.y));
+                        best_t = w0 ? t0 : best_t; q3.x = w0 ? it : q3.x; q3.y = w0 ? it : q3.y;
+                        const bool w1 = a1 && (t1 < best_t || (t1 == best_t && it > q3.y));
+                        best_t = w1 ? t1 : best_t; q3.x = w1 ? it + 1 : q3.x; q3.y = w1 ? it : q3.y;
+                        if (MODE == 0) bound = (w0 || w1) ? prune_bound(best_t) : bound;
+                    }
+                    for (int i = it + 2; i < it + nt && !done; i++) { // only with bvh_thresh_n > 2
+                        if (STATS) tc.tests++;
+                        float t;
+                        if (tri_test(sc, i, r, t)) {
+                            if (any_hit) {
+                                if (t_limit - t > CRT_EPSILON) { best_t = t; q3.x = i; done = true; }
+                            } else if (t < best_t || (t == best_t && it > q3.y)) {
+                                best_t = t; q3.x = i; q3.y = it;
+                                if (MODE == 0) bound = prune_bound(t);
+                            }
+                        }
+                    }
+                    S.r1[id].w = best_t;
+                    need_pop = !done;
+                } else {
+                    if (STATS) tc.inner++;
+                    const float4* nd = sc.nodes + (size_t)ref * 4;
+                    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+                    const F3 inv = f3(1 / d.x, 1 / d.y, 1 / d.z); // Ray.cuh:14 (same bits as start_ray computed)
+                    float tl = 0.0f, tr = 0.0f;
+                    bool hl = false, hr = false;
+                    if (MODE == 0) {
+                        hl = slab_test_finite(a, b, o, inv, tl);
+                        hr = slab_test_finite(c, e, o, inv, tr);
+                    }
+                    if (MODE == 1 || __ballot((flags & RF_EXACT) != 0)) {
+                        if (MODE == 1 || (flags & RF_EXACT)) {
+                            RayT r;
+                            r.o = o; r.d = d; r.inv = inv;
+                            const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0;
+                            hl = slab_test(a, b, r, nx, ny, nz, tl);
+                            hr = slab_test(c, e, r, nx, ny, nz, tr);
+                        }
+                    }
+                    const int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
+                    bool left_first;
+                    if (MODE == 1) {
+                        left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
+                    } else {
+                        hl = hl && !(tl > bound);
+                        hr = hr && !(tr > bound);
+                        left_first = tl <= tr;
+                    }
+                    const bool both = hl && hr, any = hl || hr;
+                    const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+                    if (both) {
+                        const int2 en = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
+                        if (sp < POOL_LV) S.stk[sp][id] = en;
+                        else M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+                        sp++;
+                        if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+                    }
+                    ref = any ? near_ref : ref;
+                    need_pop = !any;
+                }
+                // pop until a node that is still within the pruning bound
+                while (need_pop) {
+                    if (sp == 0) { done = true; break; }
+                    sp--;
+                    int2 en;
+                    if (sp < POOL_LV) en = S.stk[sp][id];
+                    else en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    ref = en.x;
+                    if (MODE == 0 && __int_as_float(en.y) > bound) continue;
+                    need_pop = false;
+                }
+                q3.z = sp | (int)flags;
+                q3.w = ref;
+                S.r3[id] = q3;
+                if (STATS && done && q3.x >= 0) tc.hits++;
+                nph = done ? route_done(flags, q3.x) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+            }
+            PUSH3()
+        } else if (act == PH3_LA) {
+            POP3(PH3_LA)
+#ifdef CRT_STAMPS
+            dg_lanes[PH3_LA] += (unsigned)take;
+#endif
+            if (on) {
+                NewRay nr;
+                nph = logic_A(P, tb, g, S.r0[id], S.r1[id], S.r3[id].x, cnt, nr);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+            }
+            PUSH3()
+        } else if (act == PH3_LB) {
+            POP3(PH3_LB)
+#ifdef CRT_STAMPS
+            dg_lanes[PH3_LB] += (unsigned)take;
+#endif
+            if (on) {
+                NewRay nr;
+                nph = logic_B(P, g, S.r0[id], S.r1[id], cnt, nr);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+            }
+            PUSH3()
+        } else {
+            POP3(PH3_LC)
+#ifdef CRT_STAMPS
+            dg_lanes[PH3_LC] += (unsigned)take;
+#endif
+            if (on) {
+                NewRay nr;
+                if (logic_C(P, tb, g, cnt, nr)) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+            }
+            PUSH3()
+        }
+        CRT_STAMP3(act)
+    }
+#undef PUSH3
+#undef POP3
+
+    // ---- counters ----
+    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
+    unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+    if (lane == 0 && (r | pa)) {
+        atomicAdd(&cs[C_RAYS], (unsigned long long)r);
+        atomicAdd(&cs[C_SHADOW], (unsigned long long)sh);
+        atomicAdd(&cs[C_PROBE], (unsigned long long)pr);
+        atomicAdd(&cs[C_PATHS], (unsigned long long)pa);
+    }
+#ifdef CRT_STAMPS
+    if (lane == 0) {
+        atomicAdd(&cs[C_CYC_LOGIC], dg_cyc[PH3_LA] + dg_cyc[PH3_LB] + dg_cyc[PH3_LC]); atomicAdd(&cs[C_CYC_LEAF], dg_cyc[PH3_LEAF]);
+        atomicAdd(&cs[C_CYC_INNER], dg_cyc[PH3_INNER]); atomicAdd(&cs[C_CYC_OTHER], dg_cyc[PH3_N]);
+        for (int i = 0; i < PH3_N; i++) {
+            atomicAdd(&cs[C_DIAG + i], (unsigned long long)dg_iter[i]); atomicAdd(&cs[C_DIAG + PH3_N + i], (unsigned long long)dg_lanes[i]);
+            atomicAdd(&cs[C_DIAG + 2 * PH3_N + i], dg_cyc[i]);
+        }
+    }
+#endif
+    if (STATS) {
+        uint32_t a = wave_sum(tc.inner), b = wave_sum(tc.leaf), c = wave_sum(tc.tests), d = wave_sum(tc.hits);
+        uint32_t ms = max_sp;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
+        if (lane == 0) {
+            atomicAdd(&cs[C_INNER], (unsigned long long)a);
+            atomicAdd(&cs[C_LEAF], (unsigned long long)b);
+            atomicAdd(&cs[C_TESTS], (unsigned long long)c);
+            atomicAdd(&cs[C_HITS], (unsigned long long)d);
             atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
         }
     }
@@ -1685,7 +2313,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        if (env_u32("CRT_PIPELINE", 3) == 1 || env_u32("CRT_PIPELINE", 3) == 3) {
+        const uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
+        if (pipeline == 1 || pipeline == 3 || pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
             const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
@@ -1705,7 +2334,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 }
 #undef CRT_MEGA_CASE
             };
-            const bool regroup = env_u32("CRT_PIPELINE", 3) == 3;
+            const bool regroup = pipeline >= 3;
+            const bool queued = pipeline == 4;
+            const uint32_t pool_p = queued ? (uint32_t)POOL3_P : (uint32_t)POOL_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
             int per_cu = 1;
@@ -1719,10 +2350,17 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<1, true>, 64, 0);
                     if (e != hipSuccess || *n < 1) *n = 1;
                 };
-                q2(&per_cu);
+                auto q3 = [&](int* n) {
+                    hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, false>, 64, 0)
+                                 : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, true>, 64, 0)
+                                 : mode_id == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, false>, 64, 0)
+                                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, true>, 64, 0);
+                    if (e != hipSuccess || *n < 1) *n = 1;
+                };
+                if (queued) q3(&per_cu); else q2(&per_cu);
                 per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
-                blocks = std::min<uint32_t>((uint32_t)((cap + POOL_P - 1) / POOL_P), (uint32_t)(sc->n_cus * per_cu));
-                lanes = blocks * (uint32_t)POOL_P; // pool slots
+                blocks = std::min<uint32_t>((uint32_t)((cap + pool_p - 1) / pool_p), (uint32_t)(sc->n_cus * per_cu));
+                lanes = blocks * pool_p; // pool slots
             } else {
                 launch_mega(M, 0, true, &per_cu);
                 per_cu = (int)std::min<uint32_t>((uint32_t)std::max(1, per_cu), env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
@@ -1772,9 +2410,21 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
                 M.P = P;
                 HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
-                if (regroup) hipLaunchKernelGGL(k_pool_init, dim3((lanes + 255) / 256), dim3(256), 0, st, pool);
+                if (regroup && !queued) hipLaunchKernelGGL(k_pool_init, dim3((lanes + 255) / 256), dim3(256), 0, st, pool);
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
-                if (regroup) {
+                if (queued) {
+                    MParams3 M3;
+                    M3.M = M;
+                    M3.thr[PH3_INNER] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_INNER", 64));
+                    M3.thr[PH3_LEAF] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LEAF", 48));
+                    M3.thr[PH3_LA] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LA", 48));
+                    M3.thr[PH3_LB] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LB", 48));
+                    M3.thr[PH3_LC] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LC", 48));
+                    if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
+                    else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
+                } else if (regroup) {
                     if (mode_id == 0) hipLaunchKernelGGL((k_mega2<0, false>), dim3(blocks), dim3(64), 0, st, M);
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega2<0, true>), dim3(blocks), dim3(64), 0, st, M);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega2<1, false>), dim3(blocks), dim3(64), 0, st, M);
@@ -1810,6 +2460,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 HIP_CHECK(hipEventElapsedTime(&total, e0, e3));
                 stats->phase_cycles[0] = counter_sum(C_CYC_LOGIC); stats->phase_cycles[1] = counter_sum(C_CYC_LEAF);
                 stats->phase_cycles[2] = counter_sum(C_CYC_INNER); stats->phase_cycles[3] = counter_sum(C_CYC_OTHER);
+                for (int i = 0; i < 20; i++) stats->phase_cycles[4 + i] = counter_sum(C_DIAG + i);
                 stats->kernel_ms = (float)kernel_ms;
                 stats->logic_ms = 0.0f;
                 stats->total_ms = total;

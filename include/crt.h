@@ -126,7 +126,8 @@ typedef struct {
     uint64_t inner_pops, leaf_pops, tri_tests, hits; /* visit counters of the traversal that ran; CRT_FLAG_STATS only
                                                          (with CRT_TRAVERSAL_REFERENCE: the reference's visit set) */
     uint64_t stack_sum, stack_max;                   /* CRT_FLAG_STATS: sum / max over rays of the traversal stack high-water */
-    uint64_t phase_cycles[4];                        /* diagnostic builds (-DCRT_STAMPS) only: wave cycles in logic / leaf / inner / other */
+    uint64_t phase_cycles[24];                       /* diagnostic builds (-DCRT_STAMPS) only: wave cycles in logic / leaf / inner / other, then
+                                                        iterations[3], gathered rays[3] (logic, inner, leaf), logic section passes[8], section lanes[6] */
     float kernel_ms;             /* sum of the HIP-event times of the traversal kernel (k_trace) launches */
     float logic_ms;              /* sum of the HIP-event times of the path-logic kernel (k_logic) launches */
     float total_ms;              /* HIP-event time of the whole device pipeline of this call */
