@@ -43,6 +43,16 @@ struct DevScene {
     int32_t root_fast;   // root of the SAH tree over the reference leaves (crt_accel.h)
     int32_t root_exact;  // root of the reference-topology tree
     int32_t n_lights;
+    // k_mega3's copies of the two trees: child pairs packed per coordinate, leaves as triangle-pair records
+    const float4* nodes3;    // 4 x float4 per inner node (same node numbering as `nodes`):
+                             //   [0] = (lo.x L, lo.x R, lo.y L, lo.y R)  [1] = (lo.z L, lo.z R, hi.x L, hi.x R)
+                             //   [2] = (hi.y L, hi.y R, hi.z L, hi.z R)  [3] = (bits(ref L), bits(ref R), 0, 0)
+                             // child ref >= 0: inner node; < 0: ~ref = first record of the leaf in leaf_geo
+    const float4* leaf_geo;  // 5 x float4 per record = two consecutive triangles a, b of one leaf:
+                             //   (v1.x a, v1.x b, v1.y a, v1.y b) (v1.z a, v1.z b, e1.x a, e1.x b) (e1.y a, e1.y b, e1.z a, e1.z b)
+                             //   (e2.x a, e2.x b, e2.y a, e2.y b) (e2.z a, e2.z b, bits(index of a), bits(triangles of the leaf from a on))
+                             // a leaf of n triangles owns ceil(n / 2) consecutive records
+    int32_t root3_fast, root3_exact;
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

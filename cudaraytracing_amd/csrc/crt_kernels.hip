@@ -1311,7 +1311,9 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
 // --------------------------------------- megakernel, queued sub-phases ----
 // k_mega2 spends 22 % of its cycles in a logic phase whose sections each serve 20-60 % of the gathered
 // lanes, 11 % in the census / permute gather, and its inner-node batches average 47 of 64 lanes
-// (-DCRT_STAMPS counters).  k_mega3 keeps the wave-private LDS ray pool and changes three things:
+// (-DCRT_STAMPS counters).  Sensitivity probes (tools/diag_sens.sh) show the kernel is bound by vector
+// instruction ISSUE: every wave instruction added to the inner step costs ~5 SIMD cycles, additively, so
+// the design goal of k_mega3 is instructions per ray:
 //   * regrouping by QUEUES: every phase owns a ring of ray ids in LDS; a batch is the 64 oldest ids of the
 //     chosen ring (one ds_read_u8), and a processed ray is appended to the ring of its new phase at
 //     count + prefix-popcount of the ballot (one ds_write_b8).  Counts and heads are wave-uniform scalars;
@@ -1322,10 +1324,16 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
 //       LC  path ends (miss / emitter / roulette) -> backward recursion, next work item, camera ray
 //     the traversal step routes a finished ray from flag bits in its LDS record; a phase that finds the
 //     path belongs elsewhere (emitter found in LA, roulette stop in LB) parks it there without a ray.
-//   * rays whose origin, direction and 1/direction are all finite (all but a handful) test boxes with
-//     v_min / v_max / v_min3 / v_max3: for finite operands min(t_lo, t_hi) IS the reference's sign-selected
-//     entry distance (rounding is monotone), so the bits are the same; the others keep the reference
-//     formula with its NaN behaviour (DeviceBVH.cuh:97-121) and walk the reference topology.
+//   * 1/direction lives in the LDS record (76 B per ray: origin, direction, 1/direction, one distance,
+//     best triangle, node, flags, 3 stack levels, ring slots), so the inner step has no divisions;
+//   * inner nodes are stored as (left, right) PAIRS per coordinate, so that both child boxes go through
+//     v_pk_add_f32 / v_pk_mul_f32 together; rays whose origin, direction and 1/direction are all finite
+//     (all but a handful) finish the test with v_min / v_max / v_min3 / v_max3: for finite operands
+//     min(t_lo, t_hi) IS the reference's sign-selected entry distance (rounding is monotone), so the bits
+//     are the same; the others keep the reference formula with its NaN behaviour (DeviceBVH.cuh:97-121)
+//     and walk the reference topology;
+//   * the (<= 2) triangles of a leaf are one 80 B record, both Moeller-Trumbore tests run as one packed
+//     computation (same operations per triangle, two at a time).
 #define PH3_INNER 0
 #define PH3_LEAF 1
 #define PH3_LA 2
@@ -1335,30 +1343,37 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
 #define PH3_NONE 7
 #define ST_FIN 5   /* path complete, backward recursion pending (q bit 0: the deepest vertex is an emitter) */
 #define ST_NEED 6  /* vertex entered with zero next-event samples: straight to roulette */
+// word D of the ray record: traversal stack depth (bits 0-7), best triangle - first triangle of its leaf (bits 8-15), flags
 #define RF_ANYHIT 0x10000   /* traversal stops at the first accepted hit closer than the light */
 #define RF_SHADOW 0x20000   /* the ray is a next-event sample ... */
 #define RF_LAST 0x40000     /* ... and the last one of its vertex */
 #define RF_PROBE 0x80000    /* SPECULAR emitter probe */
 #define RF_EXACT 0x100000   /* reference box arithmetic (non-finite operands) */
+#define RF_HASHIT 0x200000  /* closest-hit ray: a hit is recorded (T = its distance) */
 #ifndef POOL3_P
-#define POOL3_P 128
+#define POOL3_P 126         /* 126 x 76 B + rings = 10 216 B: 16 waves per CU */
 #endif
 #define POOL3_QCAP 128      /* ring capacity: power of two >= POOL3_P, ids fit a byte */
 #if POOL3_P > POOL3_QCAP || POOL3_QCAP > 256
 #error "POOL3_QCAP must be a power of two in [POOL3_P, 256]"
 #endif
+#define CRT_MEGA3_MAX_LEAF 255 /* best-triangle offset inside its leaf is kept in 8 bits */
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct Pool3Lds {
-    float4 r0[POOL3_P];          // origin.xyz, t_limit
-    float4 r1[POOL3_P];          // direction.xyz, best_t
-    int4 r3[POOL3_P];            // best_tri, best_leaf, sp | RF_* flags, current node ref
+    float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
+    float4 B[POOL3_P];           // direction.xyz, bits(best triangle, -1 = none)
+    float4 C[POOL3_P];           // 1/direction.xyz (Ray.cuh:14), bits(current node ref)
     int2 stk[POOL_LV][POOL3_P];  // traversal stack (node ref, t_enter); deeper levels spill to global memory
+    uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N][POOL3_QCAP];
 };
 
 struct MParams3 {
     MParams M;
     int32_t thr[PH3_N]; // a phase runs as soon as this many rays wait for it (else the fullest one does)
+    int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
 struct NewRay {
@@ -1369,16 +1384,8 @@ struct NewRay {
 
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-// hit_AABB (DeviceBVH.cuh:87-126) for operands that are all finite: same products, entry = per-axis minimum
-__device__ __forceinline__ bool slab_test_finite(float4 lo, float4 hi, F3 o, F3 inv, float& t_enter)
-{
-    const float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-    const float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-    const float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-    t_enter = fmax3(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1), __builtin_fminf(z0, z1));
-    const float t_exit = fmin3(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1), __builtin_fmaxf(z0, z1));
-    return t_enter <= t_exit + CRT_EPSILON && t_exit >= 0;
-}
+__device__ __forceinline__ v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f v2s(float a) { v2f r; r.x = a; r.y = a; return r; }
 
 // Where a ray goes once its traversal is over.
 __device__ __forceinline__ uint32_t route_done(uint32_t flags, int best_tri)
@@ -1396,31 +1403,43 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     cnt.probe += (nr.flags & RF_PROBE) ? 1u : 0u;
     const F3 inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z); // Ray.cuh:14
     uint32_t flags = nr.flags;
-    const bool finite = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX &&
-                        absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX; // a finite 1/d has a finite d
-    if (MODE == 1 || !finite) flags |= RF_EXACT;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
-    const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX;
-    const int ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
+    const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX; // a finite 1/d has a finite d
+    const bool finite = finite_inv && absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX;
+    if (MODE == 1 || !finite) flags |= RF_EXACT;
+    const int ref = (MODE == 0 && finite_inv) ? sc.root3_fast : sc.root3_exact;
     bool answered = false;
+    float T = FLT_MAX;
     if (MODE == 0 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
         flags |= RF_ANYHIT;
+        T = nr.tl;
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         answered = !(nr.tl == nr.tl) || nr.tl == -pinf();
     }
-    S.r0[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.tl);
-    S.r1[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, FLT_MAX);
-    S.r3[id] = make_int4(-1, -1, (int)flags, ref);
+    S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, T);
+    S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
+    S.C[id] = make_float4(inv.x, inv.y, inv.z, __int_as_float(ref));
+    S.D[id] = flags;
     if (answered) return route_done(flags, -1);
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
+}
+
+// Visibility of a next-event sample (Render.cuh:19-27, :272): tl - hit.t > EPSILON with hit.t = FLT_MAX when nothing was
+// hit.  An any-hit ray only ever records hits that satisfy the comparison, so its answer is "recorded a hit", plus the
+// reference's own quirk that an infinite limit minus FLT_MAX is still "blocked".
+template <int MODE>
+__device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
+{
+    if (MODE == 0) return tri >= 0 || tl - FLT_MAX > CRT_EPSILON;
+    return tl - T > CRT_EPSILON;
 }
 
 // LA: consumes the result of a next-event sample that is not the last one of its vertex, of a closest-hit ray
 // that found a surface, or of a probe ray; enters the vertex if it is new; sets up the next next-event sample.
 // Returns PH3_NONE when a ray was emitted into nr, else the phase the path has to visit instead.
-__device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 q0, const float4 q1, const int res_tri,
-                                            PathCounters& cnt, NewRay& nr)
+template <int MODE>
+__device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const DevScene& sc = P.sc;
     const Pool& pl = P.pool;
@@ -1429,22 +1448,22 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     const float4 vn = pl.vn[g];
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
-    const float res_t = q1.w;
+    const float res_t = qa.w;
+    const int res_tri = __float_as_int(qb.w);
     Lane s;
     s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
     s.Ld = f3(la.x, la.y, la.z);
     s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
     s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
-    s.ro = f3(q0.x, q0.y, q0.z); s.tl = q0.w;
-    s.rd = f3(q1.x, q1.y, q1.z);
+    s.ro = f3(qa.x, qa.y, qa.z); s.tl = 0.0f;
+    s.rd = f3(qb.x, qb.y, qb.z);
     s.pos = s.ro; s.vtri = 0; s.c = f3(0.0f, 0.0f, 0.0f); s.kind = RAY_NONE;
-    bool do_enter = false, do_setup = false;
+    bool do_enter = false;
     if (stage == ST_SHADOW) {
-        // visibility of next-event sample q (Render.cuh:19-27, :272-284); shadow rays start at the vertex
-        const float4 cc = pl.cc[g];
-        if (!(s.tl - res_t > CRT_EPSILON)) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
+        // visibility of next-event sample q (Render.cuh:19-27, :272-284); shadow rays start at the vertex: s.pos == s.ro
+        const float4 cc = pl.cc[g]; // .w = distance to the light sample
+        if (!shadow_blocked<MODE>(cc.w, res_t, res_tri)) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
         s.q++;
-        do_setup = true;
     } else if (stage == ST_HIT) {
         // the camera / bounce ray found vertex `depth` (Render.cuh:207-213)
         const F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
@@ -1519,25 +1538,24 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         }
         s.Ld = f3(0.0f, 0.0f, 0.0f);
         s.q = 0;
-        if (sc.n_lights * P.lsn > 0) do_setup = true;
-        else {
+        if (sc.n_lights * P.lsn <= 0) {
             pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
             return PH3_LB;
         }
-    } // (after a next-event sample the vertex is the origin of the shadow ray: s.pos == s.ro already)
+    }
     // next-event sample q of the current vertex
     const float4 m0 = mat_row(tb, s.mat, 0);
     setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
     pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
-    pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
+    pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, s.tl);
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
     nr.flags = RF_SHADOW | (s.q + 1 == (uint32_t)(sc.n_lights * P.lsn) ? RF_LAST : 0u);
-    (void)do_setup; (void)cnt;
     return PH3_NONE;
 }
 
 // LB: direct light of vertex `depth` is complete -> vertex record, Russian roulette, bounce (Render.cuh:210-228).
-__device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 q0, const float4 q1, PathCounters& cnt, NewRay& nr)
+template <int MODE>
+__device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const Pool& pl = P.pool;
     const float4 la = pl.la[g];
@@ -1548,7 +1566,7 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     F3 Ld = f3(la.x, la.y, la.z);
     if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
         const float4 cc = pl.cc[g];
-        if (!(q0.w - q1.w > CRT_EPSILON)) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
+        if (!shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w))) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
     pl.rec_a[(size_t)depth * pl.n + g] = make_float4(Ld.x, Ld.y, Ld.z, 0.0f);
     bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
@@ -1567,12 +1585,11 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     depth++;
     pl.la[g] = make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8)));
     nr.o = f3(vx.x, vx.y, vx.z); nr.d = unit3(ndir); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
-    (void)cnt;
     return PH3_NONE;
 }
 
 // LC: the path is complete (miss, emitter, roulette, stack full) -> backward recursion (Render.cuh:238-326), next
-// work item and its camera ray (Render.cuh:344-347).  Returns PH3_NONE with a ray in nr, or PH3_LC + dead = true.
+// work item and its camera ray (Render.cuh:344-347).  Returns false when the work items are exhausted (the ray slot dies).
 __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr)
 {
     const Pool& pl = P.pool;
@@ -1613,6 +1630,56 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         nr.o = f3(P.eye[0], P.eye[1], P.eye[2]); nr.d = unit3(wd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
         return true;
     }
+}
+
+// Both child boxes of an inner node at once (hit_AABB, DeviceBVH.cuh:87-126); lane .x = left child, .y = right child.
+// Node layout: crt_device.h (nodes3).  exact = reference arithmetic (sign-selected planes, x<y?x:y minima) for rays with
+// non-finite operands; otherwise minima / maxima of the two plane distances, which are the same numbers.
+__device__ __forceinline__ void slab_pair(const float4 n0, const float4 n1, const float4 n2, const F3 o, const F3 inv, const F3 d, const bool exact,
+                                          bool& hl, bool& hr, float& tl, float& tr)
+{
+    const v2f tx0 = (v2(n0.x, n0.y) - v2s(o.x)) * v2s(inv.x), ty0 = (v2(n0.z, n0.w) - v2s(o.y)) * v2s(inv.y), tz0 = (v2(n1.x, n1.y) - v2s(o.z)) * v2s(inv.z);
+    const v2f tx1 = (v2(n1.z, n1.w) - v2s(o.x)) * v2s(inv.x), ty1 = (v2(n2.x, n2.y) - v2s(o.y)) * v2s(inv.y), tz1 = (v2(n2.z, n2.w) - v2s(o.z)) * v2s(inv.z);
+    float el, er, xl, xr;
+    if (!exact) {
+        el = fmax3(__builtin_fminf(tx0.x, tx1.x), __builtin_fminf(ty0.x, ty1.x), __builtin_fminf(tz0.x, tz1.x));
+        er = fmax3(__builtin_fminf(tx0.y, tx1.y), __builtin_fminf(ty0.y, ty1.y), __builtin_fminf(tz0.y, tz1.y));
+        xl = fmin3(__builtin_fmaxf(tx0.x, tx1.x), __builtin_fmaxf(ty0.x, ty1.x), __builtin_fmaxf(tz0.x, tz1.x));
+        xr = fmin3(__builtin_fmaxf(tx0.y, tx1.y), __builtin_fmaxf(ty0.y, ty1.y), __builtin_fmaxf(tz0.y, tz1.y));
+    } else {
+        const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0; // the swap of DeviceBVH.cuh:101-119
+        el = maxf_ref(maxf_ref(nx ? tx1.x : tx0.x, ny ? ty1.x : ty0.x), nz ? tz1.x : tz0.x);
+        er = maxf_ref(maxf_ref(nx ? tx1.y : tx0.y, ny ? ty1.y : ty0.y), nz ? tz1.y : tz0.y);
+        xl = minf_ref(minf_ref(nx ? tx0.x : tx1.x, ny ? ty0.x : ty1.x), nz ? tz0.x : tz1.x);
+        xr = minf_ref(minf_ref(nx ? tx0.y : tx1.y, ny ? ty0.y : ty1.y), nz ? tz0.y : tz1.y);
+    }
+    hl = el <= xl + CRT_EPSILON && xl >= 0;
+    hr = er <= xr + CRT_EPSILON && xr >= 0;
+    tl = el; tr = er;
+}
+
+// The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
+// the t > EPSILON filter of DeviceBVHNode::hit (DeviceBVH.cuh:37); lane .x = first triangle, .y = second.
+__device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4 g4, const F3 o, const F3 d,
+                                         bool& a0, bool& a1, float& t0, float& t1)
+{
+    const v2f v1x = v2(g0.x, g0.y), v1y = v2(g0.z, g0.w), v1z = v2(g1.x, g1.y);
+    const v2f e1x = v2(g1.z, g1.w), e1y = v2(g2.x, g2.y), e1z = v2(g2.z, g2.w);
+    const v2f e2x = v2(g3.x, g3.y), e2y = v2(g3.z, g3.w), e2z = v2(g4.x, g4.y);
+    const v2f sx = v2s(o.x) - v1x, sy = v2s(o.y) - v1y, sz = v2s(o.z) - v1z;
+    // s1 = d x e2, s2 = s x e1 (OrthoMethods.h:106-108)
+    const v2f s1x = v2s(d.y) * e2z - v2s(d.z) * e2y, s1y = v2s(d.z) * e2x - v2s(d.x) * e2z, s1z = v2s(d.x) * e2y - v2s(d.y) * e2x;
+    const v2f s2x = sy * e1z - sz * e1y, s2y = sz * e1x - sx * e1z, s2z = sx * e1y - sy * e1x;
+    const v2f det = s1x * e1x + (s1y * e1y + s1z * e1z);
+    v2f rcp;
+    rcp.x = 1 / det.x; rcp.y = 1 / det.y;
+    const v2f beta = (s1x * sx + (s1y * sy + s1z * sz)) * rcp;
+    const v2f gamma = (s2x * v2s(d.x) + (s2y * v2s(d.y) + s2z * v2s(d.z))) * rcp;
+    const v2f t = (s2x * e2x + (s2y * e2y + s2z * e2z)) * rcp;
+    const v2f alpha = v2s(1.0f) - beta - gamma;
+    a0 = 0 < alpha.x && alpha.x < 1 && 0 < beta.x && beta.x < 1 && 0 < gamma.x && gamma.x < 1 && t.x > CRT_EPSILON;
+    a1 = 0 < alpha.y && alpha.y < 1 && 0 < beta.y && beta.y < 1 && 0 < gamma.y && gamma.y < 1 && t.y > CRT_EPSILON;
+    t0 = t.x; t1 = t.y;
 }
 
 template <int MODE, bool STATS>
@@ -1696,115 +1763,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #ifdef CRT_STAMPS
         dg_iter[act]++;
 #endif
-        if (act == PH3_INNER || act == PH3_LEAF) {
-            // ---- traversal step ----
-            int take, qhead;
-            if (act == PH3_INNER) { take = min(64, qn[PH3_INNER]); qhead = qh[PH3_INNER]; qh[PH3_INNER] = (qhead + take) & (POOL3_QCAP - 1); qn[PH3_INNER] -= take; }
-            else { take = min(64, qn[PH3_LEAF]); qhead = qh[PH3_LEAF]; qh[PH3_LEAF] = (qhead + take) & (POOL3_QCAP - 1); qn[PH3_LEAF] -= take; }
-            const bool on = lane < take;
-            const uint32_t id = S.ring[act][(qhead + lane) & (POOL3_QCAP - 1)];
-            const uint32_t g = base + id;
-            uint32_t nph = PH3_NONE;
+        if (act == PH3_INNER) {
+            // ---- inner-node step: both child boxes, near child next, far child pushed with its entry distance ----
+            POP3(PH3_INNER)
 #ifdef CRT_STAMPS
-            dg_lanes[act] += (unsigned)take;
+            dg_lanes[PH3_INNER] += (unsigned)take;
 #endif
             if (on) {
-                const float4 q0 = S.r0[id], q1 = S.r1[id];
-                int4 q3 = S.r3[id];
-                const F3 o = f3(q0.x, q0.y, q0.z), d = f3(q1.x, q1.y, q1.z);
-                const float t_limit = q0.w;
-                float best_t = q1.w;
-                const uint32_t flags = (uint32_t)q3.z & 0xffff0000u;
-                int sp = q3.z & 0xffff;
-                const bool any_hit = (flags & RF_ANYHIT) != 0;
+                const float4 qa = S.A[id], qc = S.C[id];
+                const uint32_t qd = S.D[id];
+                int ref = __float_as_int(qc.w);
+                const float4* nd = sc.nodes3 + (size_t)ref * 4;
+                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
+                const float2 n3 = *(const float2*)(nd + 3);
+                const F3 o = f3(qa.x, qa.y, qa.z), inv = f3(qc.x, qc.y, qc.z);
+                int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
-                float bound = any_hit ? prune_bound(t_limit) : (MODE == 0 && q3.x >= 0 ? prune_bound(best_t) : FLT_MAX);
-                int ref = q3.w;
-                bool done = false, need_pop = false;
-                if (act == PH3_LEAF) {
-                    RayT r;
-                    r.o = o; r.d = d; r.inv = f3(0.0f, 0.0f, 0.0f); // tri_test reads o and d only
-                    const uint32_t code = (uint32_t)~ref;
-                    const int it = (int)(code >> 4);
-                    int nt = (int)(code & 15u);
-                    if (nt == 0) nt = sc.leaf_count[it];
-                    const bool two = nt > 1;
-                    float t0, t1;
-                    const bool a0 = tri_test(sc, it, r, t0);
-                    const bool a1 = tri_test(sc, two ? it + 1 : it, r, t1) && two;
-                    if (STATS) { tc.leaf++; tc.tests += two ? 2u : 1u; }
-                    if (any_hit) {
-                        const bool b0 = a0 && (t_limit - t0 > CRT_EPSILON);
-                        const bool b1 = a1 && (t_limit - t1 > CRT_EPSILON);
-                        done = b0 || b1;
-                        best_t = b0 ? t0 : (b1 ? t1 : best_t);
-                        q3.x = b0 ? it : (b1 ? it + 1 : q3.x);
-                    } else {
-                        // ascending index, strict <: the first of equal t inside a leaf wins (DeviceBVH.cuh:34-41); across leaves the
-                        // larger leaf start wins (reference visit order, see crt_trace.h)
-                        const bool w0 = a0 && (t0 < best_t || (t0 == best_t && it > q3.y));
-                        best_t = w0 ? t0 : best_t; q3.x = w0 ? it : q3.x; q3.y = w0 ? it : q3.y;
-                        const bool w1 = a1 && (t1 < best_t || (t1 == best_t && it > q3.y));
-                        best_t = w1 ? t1 : best_t; q3.x = w1 ? it + 1 : q3.x; q3.y = w1 ? it : q3.y;
-                        if (MODE == 0) bound = (w0 || w1) ? prune_bound(best_t) : bound;
-                    }
-                    for (int i = it + 2; i < it + nt && !done; i++) { // only with bvh_thresh_n > 2
-                        if (STATS) tc.tests++;
-                        float t;
-                        if (tri_test(sc, i, r, t)) {
-                            if (any_hit) {
-                                if (t_limit - t > CRT_EPSILON) { best_t = t; q3.x = i; done = true; }
-                            } else if (t < best_t || (t == best_t && it > q3.y)) {
-                                best_t = t; q3.x = i; q3.y = it;
-                                if (MODE == 0) bound = prune_bound(t);
-                            }
-                        }
-                    }
-                    S.r1[id].w = best_t;
-                    need_pop = !done;
+                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w) : FLT_MAX;
+                if (STATS) tc.inner++;
+                bool hl, hr;
+                float tl, tr;
+                if (MODE == 1) {
+                    const float4 qb = S.B[id];
+                    slab_pair(n0, n1, n2, o, inv, f3(qb.x, qb.y, qb.z), true, hl, hr, tl, tr);
                 } else {
-                    if (STATS) tc.inner++;
-                    const float4* nd = sc.nodes + (size_t)ref * 4;
-                    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
-                    const F3 inv = f3(1 / d.x, 1 / d.y, 1 / d.z); // Ray.cuh:14 (same bits as start_ray computed)
-                    float tl = 0.0f, tr = 0.0f;
-                    bool hl = false, hr = false;
-                    if (MODE == 0) {
-                        hl = slab_test_finite(a, b, o, inv, tl);
-                        hr = slab_test_finite(c, e, o, inv, tr);
-                    }
-                    if (MODE == 1 || __ballot((flags & RF_EXACT) != 0)) {
-                        if (MODE == 1 || (flags & RF_EXACT)) {
-                            RayT r;
-                            r.o = o; r.d = d; r.inv = inv;
-                            const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0;
-                            hl = slab_test(a, b, r, nx, ny, nz, tl);
-                            hr = slab_test(c, e, r, nx, ny, nz, tr);
+                    slab_pair(n0, n1, n2, o, inv, o, false, hl, hr, tl, tr);
+                    if (__ballot((qd & RF_EXACT) != 0)) { // a handful of rays per frame
+                        if (qd & RF_EXACT) {
+                            const float4 qb = S.B[id];
+                            slab_pair(n0, n1, n2, o, inv, f3(qb.x, qb.y, qb.z), true, hl, hr, tl, tr);
                         }
                     }
-                    const int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-                    bool left_first;
-                    if (MODE == 1) {
-                        left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
-                    } else {
-                        hl = hl && !(tl > bound);
-                        hr = hr && !(tr > bound);
-                        left_first = tl <= tr;
-                    }
-                    const bool both = hl && hr, any = hl || hr;
-                    const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
-                    if (both) {
-                        const int2 en = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
-                        if (sp < POOL_LV) S.stk[sp][id] = en;
-                        else M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
-                        sp++;
-                        if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-                    }
-                    ref = any ? near_ref : ref;
-                    need_pop = !any;
                 }
-                // pop until a node that is still within the pruning bound
-                while (need_pop) {
+#ifdef CRT_STAMPS
+                {
+                    float dbg_acc = 0.0f;
+                    for (int x = 0; x < M3.dbg_loads; x++) dbg_acc += sc.nodes3[(size_t)(ref ^ (x + 1)) * 4 + (x & 3)].x; // sensitivity probe: more divergent 16 B loads
+                    for (int x = 0; x < M3.dbg_valu; x++) dbg_acc = dbg_acc * 1.0001f + inv.x;                            // sensitivity probe: more VALU
+                    if (dbg_acc == 1.2345e-30f) tl = 0.0f;
+                }
+#endif
+                const int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
+                bool left_first;
+                if (MODE == 1) {
+                    left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
+                } else {
+                    hl = hl && !(tl > bound);
+                    hr = hr && !(tr > bound);
+                    left_first = tl <= tr;
+                }
+                const bool both = hl && hr, any = hl || hr;
+                const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+                if (both) {
+                    const int2 en = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
+                    if (sp < POOL_LV) S.stk[sp][id] = en;
+                    else M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+                    sp++;
+                    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+                }
+                ref = any ? near_ref : ref;
+                bool done = false, need_pop = !any;
+                while (need_pop) { // pop until a node that is still within the pruning bound
                     if (sp == 0) { done = true; break; }
                     sp--;
                     int2 en;
@@ -1814,11 +1833,83 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     if (MODE == 0 && __int_as_float(en.y) > bound) continue;
                     need_pop = false;
                 }
-                q3.z = sp | (int)flags;
-                q3.w = ref;
-                S.r3[id] = q3;
-                if (STATS && done && q3.x >= 0) tc.hits++;
-                nph = done ? route_done(flags, q3.x) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                S.C[id].w = __int_as_float(ref);
+                S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
+                if (done) {
+                    const int tri = __float_as_int(S.B[id].w);
+                    if (STATS && tri >= 0) tc.hits++;
+                    nph = route_done(qd, tri);
+                } else {
+                    nph = ref >= 0 ? PH3_INNER : PH3_LEAF;
+                }
+            }
+            PUSH3()
+        } else if (act == PH3_LEAF) {
+            // ---- leaf step: the record's two triangles in one packed computation ----
+            POP3(PH3_LEAF)
+#ifdef CRT_STAMPS
+            dg_lanes[PH3_LEAF] += (unsigned)take;
+#endif
+            if (on) {
+                const float4 qa = S.A[id], qb = S.B[id];
+                int ref = __float_as_int(S.C[id].w);
+                uint32_t qd = S.D[id];
+                const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
+                float T = qa.w;
+                int tri = __float_as_int(qb.w);
+                int sp = (int)(qd & 0xffu);
+                const bool any_hit = (qd & RF_ANYHIT) != 0;
+                int best_leaf = tri - (int)((qd >> 8) & 0xffu); // first triangle of the leaf that holds the best hit (-1 - 0 if none)
+                bool done = false;
+                uint32_t rec = (uint32_t)~ref;
+                int it0 = 0, left = 1;
+                for (int k = 0; left > 0 && !done; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
+                    const float4* lg = sc.leaf_geo + (size_t)rec * 5;
+                    const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
+                    const int it = __float_as_int(g4.z);
+                    if (k == 0) { it0 = it; left = __float_as_int(g4.w); }
+                    const bool two = left > 1;
+                    bool a0, a1;
+                    float t0, t1;
+                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
+                    a1 = a1 && two;
+                    if (STATS) { tc.tests += two ? 2u : 1u; }
+                    if (any_hit) {
+                        const bool b0 = a0 && (T - t0 > CRT_EPSILON);
+                        const bool b1 = a1 && (T - t1 > CRT_EPSILON);
+                        done = b0 || b1;
+                        tri = b0 ? it : (b1 ? it + 1 : tri);
+                    } else {
+                        // ascending index, strict <: the first of equal t inside a leaf wins (DeviceBVH.cuh:34-41); across leaves the
+                        // larger leaf start wins (reference visit order, see crt_trace.h)
+                        const bool w0 = a0 && (t0 < T || (t0 == T && it0 > best_leaf));
+                        T = w0 ? t0 : T; tri = w0 ? it : tri; best_leaf = w0 ? it0 : best_leaf;
+                        const bool w1 = a1 && (t1 < T || (t1 == T && it0 > best_leaf));
+                        T = w1 ? t1 : T; tri = w1 ? it + 1 : tri; best_leaf = w1 ? it0 : best_leaf;
+                    }
+                    left -= 2;
+                }
+                if (STATS) tc.leaf++;
+                if (!any_hit && tri >= 0) qd |= RF_HASHIT;
+                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(T) : FLT_MAX;
+                bool need_pop = !done;
+                while (need_pop) { // pop until a node that is still within the pruning bound
+                    if (sp == 0) { done = true; break; }
+                    sp--;
+                    int2 en;
+                    if (sp < POOL_LV) en = S.stk[sp][id];
+                    else en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    ref = en.x;
+                    if (MODE == 0 && __int_as_float(en.y) > bound) continue;
+                    need_pop = false;
+                }
+                qd = (qd & 0xffff0000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xff00u) | (uint32_t)sp;
+                if (!any_hit) S.A[id].w = T;
+                S.B[id].w = __int_as_float(tri);
+                S.C[id].w = __int_as_float(ref);
+                S.D[id] = qd;
+                if (STATS && done && tri >= 0) tc.hits++;
+                nph = done ? route_done(qd, tri) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
             }
             PUSH3()
         } else if (act == PH3_LA) {
@@ -1828,7 +1919,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
             if (on) {
                 NewRay nr;
-                nph = logic_A(P, tb, g, S.r0[id], S.r1[id], S.r3[id].x, cnt, nr);
+                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
             }
             PUSH3()
@@ -1839,7 +1930,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
             if (on) {
                 NewRay nr;
-                nph = logic_B(P, g, S.r0[id], S.r1[id], cnt, nr);
+                nph = logic_B<MODE>(P, g, S.A[id], S.B[id], nr);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
             }
             PUSH3()
@@ -2047,7 +2138,8 @@ const int kMaxBatch = 64;
 
 struct crt_scene {
     int device = 0;
-    DevBuf<float4> nodes, tri_geo, mats, ltri;
+    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo;
+    uint32_t max_leaf = 0; // triangles in the largest leaf
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint4> lights;
     // path pool + per-item radiance + cross-chunk accumulator
@@ -2313,7 +2405,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        const uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
+        uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
+        if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 3; // k_mega3 keeps the best triangle's offset in its leaf in 8 bits
         if (pipeline == 1 || pipeline == 3 || pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
@@ -2420,6 +2513,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     M3.thr[PH3_LA] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LA", 48));
                     M3.thr[PH3_LB] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LB", 48));
                     M3.thr[PH3_LC] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LC", 48));
+                    M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
+                    if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
+                    if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
                     if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
@@ -2684,6 +2780,43 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             ltri[i * 4ull + 2] = make_float4(t.v3[2], t.normal[0], t.normal[1], t.normal[2]);
             ltri[i * 4ull + 3] = make_float4(m.ke[0], m.ke[1], m.ke[2], t.area_of_obj);
         }
+        // ---- k_mega3 layouts (crt_device.h): triangle-pair records per leaf, child boxes as (left, right) pairs ----
+        std::vector<float4> leaf_geo, nodes3(nodes.size());
+        std::vector<int32_t> rec_of_it(d->n_tris, -1);
+        uint32_t max_leaf = 0;
+        for (uint32_t i = 0; i < d->n_nodes; i++) {
+            const crt_bvh_node& nn = d->nodes[i];
+            if (!(nn.lc < 0 && nn.rc < 0)) continue;
+            max_leaf = std::max(max_leaf, nn.n);
+            rec_of_it[nn.it] = (int32_t)(leaf_geo.size() / 5);
+            for (uint32_t k = 0; k < nn.n; k += 2) {
+                const uint32_t ia = (uint32_t)nn.it + k, ib = k + 1 < nn.n ? ia + 1 : ia; // odd tail: the second lane repeats a and is masked
+                const float4 a0 = geo[ia * 3ull], a1 = geo[ia * 3ull + 1], a2 = geo[ia * 3ull + 2];
+                const float4 b0 = geo[ib * 3ull], b1 = geo[ib * 3ull + 1], b2 = geo[ib * 3ull + 2];
+                leaf_geo.push_back(make_float4(a0.x, b0.x, a0.y, b0.y));  // v1.x, v1.y
+                leaf_geo.push_back(make_float4(a0.z, b0.z, a0.w, b0.w));  // v1.z, e1.x
+                leaf_geo.push_back(make_float4(a1.x, b1.x, a1.y, b1.y));  // e1.y, e1.z
+                leaf_geo.push_back(make_float4(a1.z, b1.z, a1.w, b1.w));  // e2.x, e2.y
+                leaf_geo.push_back(make_float4(a2.x, b2.x, as_float((int32_t)ia), as_float((int32_t)(nn.n - k)))); // e2.z, index, remaining
+            }
+        }
+        auto ref3 = [&](int32_t r) -> int32_t { // old child ref -> k_mega3 child ref
+            if (r >= 0) return r;
+            return ~rec_of_it[(uint32_t)~r >> 4];
+        };
+        for (size_t q = 0; q * 4 < nodes.size(); q++) {
+            const float4 a = nodes[q * 4], b = nodes[q * 4 + 1], c = nodes[q * 4 + 2], e = nodes[q * 4 + 3];
+            int32_t lr, rr;
+            std::memcpy(&lr, &a.w, 4); std::memcpy(&rr, &b.w, 4);
+            nodes3[q * 4 + 0] = make_float4(a.x, c.x, a.y, c.y);
+            nodes3[q * 4 + 1] = make_float4(a.z, c.z, b.x, e.x);
+            nodes3[q * 4 + 2] = make_float4(b.y, e.y, b.z, e.z);
+            nodes3[q * 4 + 3] = make_float4(as_float(ref3(lr)), as_float(ref3(rr)), 0.0f, 0.0f);
+        }
+        sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo);
+        sc->max_leaf = max_leaf;
+        sc->dev.nodes3 = sc->nodes3.p; sc->dev.leaf_geo = sc->leaf_geo.p;
+        sc->dev.root3_fast = ref3(root_fast); sc->dev.root3_exact = ref3(root_exact);
         std::vector<uint4> lights(d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; i++) {
             FastDiv fd = make_fastdiv(d->lights[i].count);
