@@ -1387,11 +1387,11 @@ __device__ __forceinline__ float fmax3(float a, float b, float c) { return __bui
 __device__ __forceinline__ v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ v2f v2s(float a) { v2f r; r.x = a; r.y = a; return r; }
 
-// Where a ray goes once its traversal is over.
-__device__ __forceinline__ uint32_t route_done(uint32_t flags, int best_tri)
+// Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
+// or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
+__device__ __forceinline__ uint32_t route_done(uint32_t flags)
 {
-    if (flags & RF_SHADOW) return (flags & RF_LAST) ? PH3_LB : PH3_LA;
-    return ((flags & RF_PROBE) || best_tri >= 0) ? PH3_LA : PH3_LC;
+    return (flags & RF_SHADOW) ? ((flags & RF_LAST) ? PH3_LB : PH3_LA) : ((flags & (RF_PROBE | RF_HASHIT)) ? PH3_LA : PH3_LC);
 }
 
 // Writes the new ray into the pool record `id` and returns its first phase.
@@ -1421,7 +1421,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
     S.C[id] = make_float4(inv.x, inv.y, inv.z, __int_as_float(ref));
     S.D[id] = flags;
-    if (answered) return route_done(flags, -1);
+    if (answered) return route_done(flags);
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
 }
 
@@ -1705,8 +1705,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     unsigned dg_iter[PH3_N] = {0, 0, 0, 0, 0}, dg_lanes[PH3_N] = {0, 0, 0, 0, 0};
     unsigned long long dg_prev = __builtin_amdgcn_s_memtime();
 #define CRT_STAMP3(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_cyc[i] += t_now - dg_prev; dg_prev = t_now; }
+    // sections of the inner step: [0] ring id arrived, [1] record arrived, [2] node arrived, [3] boxes + push, [4] pop, [5] write-back + ring append
+    unsigned long long dg_sec[6] = {0, 0, 0, 0, 0, 0}, dg_t0 = 0;
+#define CRT_SEC3(i, dep) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(dep) : "memory"); unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_sec[i] += t_now - dg_t0; dg_t0 = t_now; }
 #else
 #define CRT_STAMP3(i)
+#define CRT_SEC3(i, dep)
 #endif
 
     // ring state: wave-uniform scalars
@@ -1726,7 +1730,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // appends the processed rays (lane active = `on`, ray `id`) to the ring of their new phase
 #define PUSH3()                                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PH3_N; p++) {                                                                    \
-        const bool mine = on && nph == (uint32_t)p;                                                                        \
+        const bool mine = nph == (uint32_t)p; /* lanes without a ray carry PH3_NONE */                                                                        \
         const unsigned long long m = __ballot(mine);                                                                       \
         if (m) {                                                                                                           \
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
@@ -1745,19 +1749,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t nph = PH3_NONE;
 
     for (;;) {
-        // ---- choose a phase: the first (logic first: it feeds the traversal) that has a full batch waiting, else the fullest ----
-        int act = -1;
-        if (qn[PH3_LC] >= M3.thr[PH3_LC]) act = PH3_LC;
-        else if (qn[PH3_LA] >= M3.thr[PH3_LA]) act = PH3_LA;
-        else if (qn[PH3_LB] >= M3.thr[PH3_LB]) act = PH3_LB;
-        else if (qn[PH3_LEAF] >= M3.thr[PH3_LEAF]) act = PH3_LEAF;
-        else if (qn[PH3_INNER] >= M3.thr[PH3_INNER]) act = PH3_INNER;
-        else {
-            int best = 0;
-#pragma unroll
-            for (int p = 0; p < PH3_N; p++)
-                if (qn[p] > best) { best = qn[p]; act = p; }
-            if (act < 0) break; // every ray of the pool is dead
+        // ---- choose a phase: the ring with the fullest batch; among equals the logic phases first (they feed the traversal), then
+        //      leaves, then inner nodes ----
+        int act;
+        {
+            // key = batch size * 8 + phase number (the phase numbers are the tie-break order)
+            const int kC = min(qn[PH3_LC], 64) * 8 + PH3_LC, kA = min(qn[PH3_LA], 64) * 8 + PH3_LA, kB = min(qn[PH3_LB], 64) * 8 + PH3_LB;
+            const int kL = min(qn[PH3_LEAF], 64) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
+            const int best = max(max(max(kC, kA), max(kB, kL)), kI);
+            if (best < 8) break; // every ray of the pool is dead
+            act = best & 7;
         }
         CRT_STAMP3(PH3_N)
 #ifdef CRT_STAMPS
@@ -1765,17 +1766,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
         if (act == PH3_INNER) {
             // ---- inner-node step: both child boxes, near child next, far child pushed with its entry distance ----
+#ifdef CRT_STAMPS
+            dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
             POP3(PH3_INNER)
 #ifdef CRT_STAMPS
             dg_lanes[PH3_INNER] += (unsigned)take;
 #endif
+            CRT_SEC3(0, id)
             if (on) {
                 const float4 qa = S.A[id], qc = S.C[id];
                 const uint32_t qd = S.D[id];
+                CRT_SEC3(1, qa.x + qc.x + __uint_as_float(qd))
                 int ref = __float_as_int(qc.w);
                 const float4* nd = sc.nodes3 + (size_t)ref * 4;
                 const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
                 const float2 n3 = *(const float2*)(nd + 3);
+                CRT_SEC3(2, n0.x + n1.x + n2.x + n3.x)
                 const F3 o = f3(qa.x, qa.y, qa.z), inv = f3(qc.x, qc.y, qc.z);
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
@@ -1817,33 +1824,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (both) {
                     const int2 en = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
                     if (sp < POOL_LV) S.stk[sp][id] = en;
-                    else M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+                    if (__ballot(sp >= POOL_LV)) {
+                        if (sp >= POOL_LV) M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+                    }
                     sp++;
                     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
                 }
                 ref = any ? near_ref : ref;
+                CRT_SEC3(3, ref + sp)
                 bool done = false, need_pop = !any;
                 while (need_pop) { // pop until a node that is still within the pruning bound
                     if (sp == 0) { done = true; break; }
                     sp--;
-                    int2 en;
-                    if (sp < POOL_LV) en = S.stk[sp][id];
-                    else en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    // the LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane
+                    // choice between the two address spaces would compile to a flat load that waits on both memory pipes
+                    int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
+                    if (__ballot(sp >= POOL_LV)) {
+                        if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    }
                     ref = en.x;
                     if (MODE == 0 && __int_as_float(en.y) > bound) continue;
                     need_pop = false;
                 }
+                CRT_SEC3(4, ref + sp)
                 S.C[id].w = __int_as_float(ref);
                 S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
-                if (done) {
-                    const int tri = __float_as_int(S.B[id].w);
-                    if (STATS && tri >= 0) tc.hits++;
-                    nph = route_done(qd, tri);
-                } else {
-                    nph = ref >= 0 ? PH3_INNER : PH3_LEAF;
-                }
+                if (STATS && done && (qd & RF_HASHIT)) tc.hits++; // (an any-hit ray that records a hit ends in the leaf step)
+                nph = done ? route_done(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
             }
             PUSH3()
+            CRT_SEC3(5, nph)
         } else if (act == PH3_LEAF) {
             // ---- leaf step: the record's two triangles in one packed computation ----
             POP3(PH3_LEAF)
@@ -1896,9 +1906,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 while (need_pop) { // pop until a node that is still within the pruning bound
                     if (sp == 0) { done = true; break; }
                     sp--;
-                    int2 en;
-                    if (sp < POOL_LV) en = S.stk[sp][id];
-                    else en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    // the LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane
+                    // choice between the two address spaces would compile to a flat load that waits on both memory pipes
+                    int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
+                    if (__ballot(sp >= POOL_LV)) {
+                        if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+                    }
                     ref = en.x;
                     if (MODE == 0 && __int_as_float(en.y) > bound) continue;
                     need_pop = false;
@@ -1909,7 +1922,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 S.C[id].w = __int_as_float(ref);
                 S.D[id] = qd;
                 if (STATS && done && tri >= 0) tc.hits++;
-                nph = done ? route_done(qd, tri) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                nph = done ? route_done(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
             }
             PUSH3()
         } else if (act == PH3_LA) {
@@ -1967,6 +1980,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             atomicAdd(&cs[C_DIAG + i], (unsigned long long)dg_iter[i]); atomicAdd(&cs[C_DIAG + PH3_N + i], (unsigned long long)dg_lanes[i]);
             atomicAdd(&cs[C_DIAG + 2 * PH3_N + i], dg_cyc[i]);
         }
+        for (int i = 0; i < 5; i++) atomicAdd(&cs[C_DIAG + 3 * PH3_N + i], dg_sec[i]); // [5] = the inner phase's total minus these
+    }
+    if (lane == 0 && false) {
     }
 #endif
     if (STATS) {
