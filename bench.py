@@ -14,12 +14,12 @@ A ray is one closest-hit query of the reference (DeviceBVH::intersect): primary,
 bounce, shadow and specular-probe rays; the count is deterministic given
 (scene, config, seed) and comes from the kernel's counters.
 
-roofline (dominant kernel: k_mega2, the persistent path-tracing megakernel, one
+roofline (dominant kernel: k_mega3, the persistent path-tracing megakernel, one
 launch per frame): algorithmic bytes per ray B_ray = 64 B x
 inner-node visits + 8 B x leaf visits + 36 B x triangle tests + 16 B x hits of
 the REFERENCE traversal's visit set, measured with the
 exhaustive counting kernel on a spp=8 slice of the same frame; achieved =
-(rays per launch x B_ray) / (average k_mega2 launch duration from HIP events on
+(rays per launch x B_ray) / (average k_mega3 launch duration from HIP events on
 the launching stream); peak = 8 TB/s HBM3E.  The production traversal walks a
 SAH tree over the reference's leaves and prunes, so it touches far fewer nodes
 than the reference's visit set: `achieved_visited` prices the nodes it really
@@ -156,7 +156,7 @@ def main():
         achieved_visited = rays_launch * b_ray_visited / (k_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                    "kernel": "k_mega2", "launches_per_frame": launches, "avg_launch_ms": round(k_ms, 4),
+                    "kernel": "k_mega3", "launches_per_frame": launches, "avg_launch_ms": round(k_ms, 4),
                     "kernel_ms_per_frame": round(k_ms_total, 3), "logic_kernel_ms_per_frame": round(float(np.mean(logic_ms)), 3),
                     "rays_per_launch": int(rays_launch), "bytes_per_ray": round(b_ray, 1),
                     "reference_visits_per_ray": ref_visits,

@@ -1372,7 +1372,6 @@ struct Pool3Lds {
 
 struct MParams3 {
     MParams M;
-    int32_t thr[PH3_N]; // a phase runs as soon as this many rays wait for it (else the fullest one does)
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
@@ -2524,11 +2523,6 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 if (queued) {
                     MParams3 M3;
                     M3.M = M;
-                    M3.thr[PH3_INNER] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_INNER", 64));
-                    M3.thr[PH3_LEAF] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LEAF", 48));
-                    M3.thr[PH3_LA] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LA", 48));
-                    M3.thr[PH3_LB] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LB", 48));
-                    M3.thr[PH3_LC] = (int32_t)std::min<uint32_t>(64, env_u32("CRT_THR_LC", 48));
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
