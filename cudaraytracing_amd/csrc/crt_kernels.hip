@@ -837,14 +837,11 @@ __global__ __launch_bounds__(256) void k_trace(const TParams T)
     }
 }
 
-// ------------------------------------------------------------ megakernel ----
-// Fused form of the two kernels above: one persistent launch per chunk.  Every lane owns one
-// path slot for the whole launch (slot = global thread id, so all plane accesses are perfectly
-// coalesced); when its ray finishes the lane parks, and as soon as MEGA_LOGIC_MIN lanes of the
-// wave are parked they run logic_advance together and re-enter the traversal with the new ray
-// in registers.  Rays and results never touch memory, there are no rounds, no relaunches and no
-// per-round drain; the path state planes (80 B per lane + 32 B vertex records) stay L2 / MALL
-// resident because there are only as many slots as resident lanes.
+// ----------------------------------------------------------- megakernels ----
+// Fused forms of the two kernels above: one persistent launch per chunk, path logic and traversal in the same
+// waves, rays and results never leave the chip (no rounds, no relaunches, no per-round drain); the path state planes
+// (80 B per path + 32 B vertex records) stay L2 / MALL resident because there are only as many paths as resident
+// rays.  (The first such kernel kept one ray per lane in registers: 42 % lane utilisation, removed.)
 struct MParams {
     LParams P;
     DevScene sc;
@@ -854,160 +851,6 @@ struct MParams {
     int32_t stack_cap;
     int32_t logic_min, leaf_min;
 };
-
-#ifndef CRT_MEGA_WAVES
-#define CRT_MEGA_WAVES 4
-#endif
-template <int MODE, bool STATS, bool LDS_TABLES>
-__global__ __launch_bounds__(256, CRT_MEGA_WAVES) void k_mega(const MParams M)
-{
-    extern __shared__ int2 s_lds2[];
-    const LParams& P = M.P;
-    const DevScene& sc = M.sc;
-    const Pool& pl = P.pool;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint32_t slot = blockIdx.x * 256u + tid;
-    __shared__ uint32_t s_cnt[5];
-    __shared__ float4 s_mats[LDS_TABLES ? LOGIC_TABLE_MAX * 3 : 1];
-    __shared__ uint4 s_lights[LDS_TABLES ? LOGIC_TABLE_MAX : 1];
-    Tables<LDS_TABLES> tb;
-    if (LDS_TABLES) {
-        if (threadIdx.x < (uint32_t)P.n_mats * 3u) s_mats[threadIdx.x] = sc.mats[threadIdx.x];
-        if (threadIdx.x < (uint32_t)sc.n_lights) s_lights[threadIdx.x] = sc.lights[threadIdx.x];
-        tb.mats = s_mats; tb.lights = s_lights;
-    } else {
-        tb.mats = sc.mats; tb.lights = sc.lights;
-    }
-    if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    TravStack S;
-    S.lds = s_lds2 + tid;
-    S.spill = M.spill + slot;
-    S.spill_stride = M.spill_stride;
-    S.cap = M.stack_cap;
-
-    PathCounters cnt;
-    cnt = PathCounters{};
-    TravCounters tc;
-    tc.inner = tc.leaf = tc.tests = tc.hits = 0;
-    uint32_t max_sp = 0, sum_sp = 0, ray_sp = 0;
-
-    int state = TR_IDLE;
-    bool dead = slot >= pl.n;
-    uint32_t stage = ST_NEW; // stage the parked lane is in (what its last ray was for)
-    TravLane L;
-    L.slot = slot; L.ref = 0; L.sp = 0; L.best_tri = -1; L.best_leaf = -1; L.best_t = FLT_MAX; L.bound = FLT_MAX; L.t_limit = 0.0f;
-    L.any_hit = false; L.nx = L.ny = L.nz = false;
-    L.r.o = L.r.d = L.r.inv = f3(0.0f, 0.0f, 0.0f);
-
-#ifdef CRT_STAMPS
-    // diagnostic build only: shader-clock cycles this wave spends in each section (never used by any output)
-    unsigned long long cyc_logic = 0, cyc_leaf = 0, cyc_inner = 0, cyc_other = 0;
-    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
-#define CRT_STAMP(acc) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); acc += t_now - t_prev; t_prev = t_now; }
-#else
-#define CRT_STAMP(acc)
-#endif
-    for (;;) {
-        // ---- path logic for parked lanes, batched ----
-        const unsigned long long parked = __ballot(state == TR_IDLE && !dead);
-        const unsigned long long busy = __ballot(state != TR_IDLE);
-        if (parked == 0 && busy == 0) break; // every lane of the wave is dead
-        if (__popcll(parked) >= M.logic_min || busy == 0) {
-            if (state == TR_IDLE && !dead) {
-                Lane s;
-                s.stage = stage;
-                s.kind = RAY_NONE;
-                s.ro = L.r.o; s.rd = L.r.d; s.tl = L.t_limit;
-                s.Ld = s.c = s.pos = s.nrm = f3(0.0f, 0.0f, 0.0f);
-                s.depth = 0; s.q = 0; s.vtri = 0; s.mat = 0; s.pixel_index = 0; s.k = 0; s.item = ITEM_NONE;
-                if (stage != ST_NEW) {
-                    float4 la = pl.la[slot], cc = pl.cc[slot], vx = pl.vx[slot], vn = pl.vn[slot];
-                    uint4 idv = pl.id[slot];
-                    uint32_t st = __float_as_uint(la.w);
-                    s.depth = st & 255u; s.q = st >> 16;
-                    s.Ld = f3(la.x, la.y, la.z);
-                    s.c = f3(cc.x, cc.y, cc.z);
-                    s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
-                    s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
-                    s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
-                }
-                const bool emitted = logic_advance(P, tb, slot, s, stage, L.best_t, L.best_tri, cnt);
-                if (emitted) {
-                    uint32_t st = s.depth | (s.stage << 8) | (s.q << 16);
-                    pl.la[slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(st));
-                    if (s.stage == ST_SHADOW) pl.cc[slot] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
-                    if (stage != ST_SHADOW) {
-                        pl.vx[slot] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
-                        pl.vn[slot] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
-                    }
-                    stage = s.stage;
-                    L.r.o = s.ro; L.r.d = s.rd;
-                    state = trav_begin<MODE>(sc, L, s.kind, s.tl); // TR_IDLE: answered without traversal, parks again
-                } else {
-                    dead = true;
-                }
-            }
-            CRT_STAMP(cyc_logic)
-            continue; // re-evaluate: lanes answered without traversal are parked again
-        }
-        CRT_STAMP(cyc_other)
-        // ---- one traversal step for the lanes in flight ----
-        bool nothing_to_do = false;
-#ifdef CRT_STAMPS
-        const bool leaf_phase_stamp = __popcll(__ballot(state == TR_LEAF)) > 0 &&
-                                      (__popcll(__ballot(state == TR_LEAF)) >= M.leaf_min || __popcll(__ballot(state == TR_INNER)) == 0);
-#endif
-        const bool finished = trav_step<MODE, STATS>(sc, L, state, S, M.leaf_min, tc, ray_sp, nothing_to_do);
-        if (finished) {
-            if (STATS) {
-                if (L.best_tri >= 0) tc.hits++;
-                if (ray_sp > max_sp) max_sp = ray_sp;
-                sum_sp += ray_sp;
-                ray_sp = 0;
-            }
-            state = TR_IDLE;
-        }
-#ifdef CRT_STAMPS
-        if (leaf_phase_stamp) { CRT_STAMP(cyc_leaf) } else { CRT_STAMP(cyc_inner) }
-#endif
-    }
-#ifdef CRT_STAMPS
-    if (lane == 0) {
-        unsigned long long* cs2 = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
-        atomicAdd(&cs2[C_CYC_LOGIC], cyc_logic); atomicAdd(&cs2[C_CYC_LEAF], cyc_leaf);
-        atomicAdd(&cs2[C_CYC_INNER], cyc_inner); atomicAdd(&cs2[C_CYC_OTHER], cyc_other);
-    }
-#endif
-
-    // ---- counters ----
-    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
-    if (lane == 0 && (r | pa)) {
-        atomicAdd(&s_cnt[0], r); atomicAdd(&s_cnt[1], sh); atomicAdd(&s_cnt[2], pr); atomicAdd(&s_cnt[3], pa);
-    }
-    __syncthreads();
-    unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
-    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) {
-        const int idx[4] = {C_RAYS, C_SHADOW, C_PROBE, C_PATHS};
-        atomicAdd(&cs[idx[threadIdx.x]], (unsigned long long)s_cnt[threadIdx.x]);
-    }
-    if (STATS) {
-        uint32_t a = wave_sum(tc.inner), b = wave_sum(tc.leaf), c = wave_sum(tc.tests), d = wave_sum(tc.hits);
-        uint32_t ss = wave_sum(sum_sp);
-        uint32_t ms = max_sp;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
-        if (lane == 0) {
-            atomicAdd(&cs[C_INNER], (unsigned long long)a);
-            atomicAdd(&cs[C_LEAF], (unsigned long long)b);
-            atomicAdd(&cs[C_TESTS], (unsigned long long)c);
-            atomicAdd(&cs[C_HITS], (unsigned long long)d);
-            atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
-            atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
-        }
-    }
-}
 
 // ----------------------------------------------- megakernel, regrouped ----
 // k_mega keeps one ray per lane, so a wave-wide phase only ever serves the lanes that happen to be in
@@ -2422,35 +2265,19 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
 
         uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
         if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 3; // k_mega3 keeps the best triangle's offset in its leaf in 8 bits
-        if (pipeline == 1 || pipeline == 3 || pipeline == 4) {
+        if (pipeline == 3 || pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
-            const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
-            const size_t lds = (size_t)lds_cap * 256 * sizeof(int2);
-            const bool lds_tables = sc->n_mats <= LOGIC_TABLE_MAX && (uint32_t)sc->dev.n_lights <= LOGIC_TABLE_MAX;
+            const int lds_cap = POOL_LV;
             const int mode_id = (reference ? 2 : 0) + (want_stats ? 1 : 0);
-            auto launch_mega = [&](const MParams& M, uint32_t blocks, bool query, int* per_cu) {
-#define CRT_MEGA_CASE(MODE, STATS, TBL)                                                                                        \
-    if (query) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_mega<MODE, STATS, TBL>, 256, lds) != hipSuccess) *per_cu = 1; } \
-    else hipLaunchKernelGGL((k_mega<MODE, STATS, TBL>), dim3(blocks), dim3(256), lds, st, M);
-                if (lds_tables) {
-                    if (mode_id == 0) { CRT_MEGA_CASE(0, false, true) } else if (mode_id == 1) { CRT_MEGA_CASE(0, true, true) }
-                    else if (mode_id == 2) { CRT_MEGA_CASE(1, false, true) } else { CRT_MEGA_CASE(1, true, true) }
-                } else {
-                    if (mode_id == 0) { CRT_MEGA_CASE(0, false, false) } else if (mode_id == 1) { CRT_MEGA_CASE(0, true, false) }
-                    else if (mode_id == 2) { CRT_MEGA_CASE(1, false, false) } else { CRT_MEGA_CASE(1, true, false) }
-                }
-#undef CRT_MEGA_CASE
-            };
-            const bool regroup = pipeline >= 3;
             const bool queued = pipeline == 4;
             const uint32_t pool_p = queued ? (uint32_t)POOL3_P : (uint32_t)POOL_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
             int per_cu = 1;
             uint32_t blocks, lanes;
-            if (regroup) {
-                // one wave per workgroup, POOL_P rays per wave
+            {
+                // one wave per workgroup, pool_p rays per wave
                 auto q2 = [&](int* n) {
                     hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<0, false>, 64, 0)
                                  : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<0, true>, 64, 0)
@@ -2469,16 +2296,11 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
                 blocks = std::min<uint32_t>((uint32_t)((cap + pool_p - 1) / pool_p), (uint32_t)(sc->n_cus * per_cu));
                 lanes = blocks * pool_p; // pool slots
-            } else {
-                launch_mega(M, 0, true, &per_cu);
-                per_cu = (int)std::min<uint32_t>((uint32_t)std::max(1, per_cu), env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
-                blocks = std::min<uint32_t>((uint32_t)((cap + 255) / 256), (uint32_t)(sc->n_cus * per_cu));
-                lanes = blocks * 256u;
             }
             sc->p_vx.ensure(lanes); sc->p_la.ensure(lanes); sc->p_cc.ensure(lanes); sc->p_vn.ensure(lanes); sc->p_id.ensure(lanes);
             sc->p_rec_a.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
             sc->p_rec_b.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
-            const int spill_levels = std::max(1, sc->stack_cap - (regroup ? POOL_LV : lds_cap));
+            const int spill_levels = std::max(1, sc->stack_cap - POOL_LV);
             sc->spill[0].ensure((size_t)spill_levels * lanes);
             Pool pool;
             std::memset(&pool, 0, sizeof(pool));
@@ -2498,8 +2320,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
             P.L = sc->L.p; P.counters = sc->counters.p; P.item_next = sc->item_next.p; P.n_mats = sc->n_mats;
             M.sc = sc->dev; M.counters = sc->counters.p; M.spill = sc->spill[0].p; M.spill_stride = lanes; M.stack_cap = lds_cap;
-            M.logic_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LOGIC_MIN", regroup ? 64 : 32));
-            M.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", regroup ? 48 : LEAF_MIN));
+            M.logic_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LOGIC_MIN", 64));
+            M.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", 48));
             AParams A;
             std::memset(&A, 0, sizeof(A));
             A.width = prm->width; A.height = prm->height; A.spp = prm->spp;
@@ -2518,7 +2340,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
                 M.P = P;
                 HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
-                if (regroup && !queued) hipLaunchKernelGGL(k_pool_init, dim3((lanes + 255) / 256), dim3(256), 0, st, pool);
+                if (!queued) hipLaunchKernelGGL(k_pool_init, dim3((lanes + 255) / 256), dim3(256), 0, st, pool);
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
                 if (queued) {
                     MParams3 M3;
@@ -2530,13 +2352,12 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
-                } else if (regroup) {
+                } else {
                     if (mode_id == 0) hipLaunchKernelGGL((k_mega2<0, false>), dim3(blocks), dim3(64), 0, st, M);
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega2<0, true>), dim3(blocks), dim3(64), 0, st, M);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega2<1, false>), dim3(blocks), dim3(64), 0, st, M);
                     else hipLaunchKernelGGL((k_mega2<1, true>), dim3(blocks), dim3(64), 0, st, M);
-                } else
-                launch_mega(M, blocks, false, nullptr);
+                }
                 HIP_CHECK(hipGetLastError());
                 if (timing) {
                     HIP_CHECK(hipEventRecord(e2, st));
