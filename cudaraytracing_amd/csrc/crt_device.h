@@ -53,6 +53,7 @@ struct DevScene {
                              //   (e2.x a, e2.x b, e2.y a, e2.y b) (e2.z a, e2.z b, bits(index of a), bits(triangles of the leaf from a on))
                              // a leaf of n triangles owns ceil(n / 2) consecutive records
     int32_t root3_fast, root3_exact;
+    const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

@@ -1367,9 +1367,9 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         do_enter = true;
     }
     if (do_enter) { // a new vertex (pos, vtri) at `depth`, reached along s.rd
-        const float4 gq = sc.tri_geo[(size_t)s.vtri * 3 + 2];
-        s.nrm = f3(gq.y, gq.z, gq.w);
-        s.mat = (uint32_t)sc.tri_mat[s.vtri];
+        const float4 gq = sc.tri_nm[s.vtri];
+        s.nrm = f3(gq.x, gq.y, gq.z);
+        s.mat = __float_as_uint(gq.w);
         pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
         pl.vx[g] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
         pl.vn[g] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
@@ -1451,7 +1451,11 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
             ke = f3(m2.x, m2.y, m2.z);
         }
         const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
-        P.L[idv.z] = make_float4(L.x, L.y, L.z, 0.0f);
+        // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
+        // and the scene in L2
+        __builtin_nontemporal_store(L.x, &P.L[idv.z].x);
+        __builtin_nontemporal_store(L.y, &P.L[idv.z].y);
+        __builtin_nontemporal_store(L.z, &P.L[idv.z].z);
     }
     for (;;) {
         const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
@@ -1996,7 +2000,7 @@ const int kMaxBatch = 64;
 
 struct crt_scene {
     int device = 0;
-    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo;
+    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm;
     uint32_t max_leaf = 0; // triangles in the largest leaf
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint4> lights;
@@ -2644,7 +2648,10 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             nodes3[q * 4 + 2] = make_float4(b.y, e.y, b.z, e.z);
             nodes3[q * 4 + 3] = make_float4(as_float(ref3(lr)), as_float(ref3(rr)), 0.0f, 0.0f);
         }
-        sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo);
+        std::vector<float4> tri_nm(d->n_tris);
+        for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
+        sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
+        sc->dev.tri_nm = sc->tri_nm.p;
         sc->max_leaf = max_leaf;
         sc->dev.nodes3 = sc->nodes3.p; sc->dev.leaf_geo = sc->leaf_geo.p;
         sc->dev.root3_fast = ref3(root_fast); sc->dev.root3_exact = ref3(root_exact);
