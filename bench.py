@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=2)
+    ap.add_argument("--cpu-spp", type=int, default=8)
     ap.add_argument("--save-png", default=None)
     args = ap.parse_args()
 
@@ -166,7 +166,8 @@ def main():
                             "walks a SAH tree over the same leaves, so frac can exceed 1; the scene is cache resident and the "
                             "kernel is bound by instruction issue / divergent 16 B loads, not by HBM (DESIGN.md)"}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        if os.path.exists(traffic_file):
+        c2 = args.scene == "cornell-box" and (args.width, args.height, args.spp) == (800, 600, 512) and world == 1
+        if c2 and os.path.exists(traffic_file):  # the PMC passes were collected on this exact workload
             try:
                 roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
             except Exception:

@@ -12,6 +12,7 @@ TRAVERSAL_FAST = 0
 TRAVERSAL_REFERENCE = 1
 FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
+FLAG_FORCE_EXACT = 4
 TILE = 8
 
 

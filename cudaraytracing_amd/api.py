@@ -151,6 +151,7 @@ class Render:
         self.spp, self.P_RR, self.light_sample_n = int(spp), np.float32(P_RR), int(light_sample_n)
         self.seed = 0
         self.traversal = capi.TRAVERSAL_FAST
+        self.extra_flags = 0  # e.g. FLAG_FORCE_EXACT (test hook)
         self.device = device
         self._h = C.c_void_p()
         capi.check(capi.lib().crt_scene_create(C.byref(scene.desc()), device, C.byref(self._h)), "crt_scene_create")
@@ -183,7 +184,7 @@ class Render:
         if not self._h:
             raise RuntimeError("Render.run_view after free()")
         cam = self._cam(eye_pos, inv_view_mat, fovY)
-        prm = self._params(flags=capi.FLAG_STATS if stats else 0, width=width, height=height)
+        prm = self._params(flags=(capi.FLAG_STATS if stats else 0) | self.extra_flags, width=width, height=height)
         w, h = prm.width, prm.height
         rgb = np.zeros((h, w, 3), dtype=np.uint8)
         mean = np.zeros((h, w, 3), dtype=np.float32) if want_mean else None

@@ -1215,6 +1215,7 @@ struct Pool3Lds {
 
 struct MParams3 {
     MParams M;
+    uint32_t force_exact;        // CRT_FLAG_FORCE_EXACT
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
@@ -1238,7 +1239,7 @@ __device__ __forceinline__ uint32_t route_done(uint32_t flags)
 
 // Writes the new ray into the pool record `id` and returns its first phase.
 template <int MODE>
-__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt)
+__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
 {
     cnt.rays++;
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
@@ -1249,8 +1250,8 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     // topology, whose box tests are the reference's own (crt_accel.h)
     const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX; // a finite 1/d has a finite d
     const bool finite = finite_inv && absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX;
-    if (MODE == 1 || !finite) flags |= RF_EXACT;
-    const int ref = (MODE == 0 && finite_inv) ? sc.root3_fast : sc.root3_exact;
+    if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
+    const int ref = (MODE == 0 && finite_inv && !force_exact) ? sc.root3_fast : sc.root3_exact;
     bool answered = false;
     float T = FLT_MAX;
     if (MODE == 0 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (on) {
                 NewRay nr;
                 nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         } else if (act == PH3_LB) {
@@ -1790,7 +1791,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (on) {
                 NewRay nr;
                 nph = logic_B<MODE>(P, g, S.A[id], S.B[id], nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         } else {
@@ -1800,7 +1801,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
             if (on) {
                 NewRay nr;
-                if (logic_C(P, tb, g, cnt, nr)) nph = start_ray<MODE>(sc, S, id, nr, cnt);
+                if (logic_C(P, tb, g, cnt, nr)) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         }
@@ -2349,6 +2350,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 if (queued) {
                     MParams3 M3;
                     M3.M = M;
+                    M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;

@@ -105,7 +105,9 @@ enum {
 };
 enum {
     CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (slower counting kernels) */
-    CRT_FLAG_TILED_OUTPUT = 2u   /* write this rank's pixels in compact 8x8-tile order instead of row-major */
+    CRT_FLAG_TILED_OUTPUT = 2u,  /* write this rank's pixels in compact 8x8-tile order instead of row-major */
+    CRT_FLAG_FORCE_EXACT = 4u    /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
+                                    box arithmetic on the reference topology, still pruned / any-hit); results are unchanged */
 };
 
 typedef struct {

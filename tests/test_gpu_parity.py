@@ -268,8 +268,8 @@ def _write_box_scene(d, n_side=6, specular=False):
     return os.path.join(d, "room.obj"), d
 
 
-def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, seed=3):
-    obj, mtl = _write_box_scene(str(tmp_path), specular=specular)
+def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, seed=3, n_side=6, extra_flags=0):
+    obj, mtl = _write_box_scene(str(tmp_path), n_side=n_side, specular=specular)
     scene = crt.Scene(w, h)
     scene.add_obj(obj, mtl)
     scene.set_BVH(thresh)
@@ -280,6 +280,7 @@ def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, 
     fov = crt.fov_to_radians(70.0)
     r = crt.Render(scene, spp, p_rr, lsn)
     r.seed = seed
+    r.extra_flags = extra_flags
     orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, p_rr, lsn, seed=seed)
     try:
         for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
@@ -297,6 +298,22 @@ def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, 
 def test_other_leaf_sizes(tmp_path, thresh):
     """bvh_thresh_n other than 2: leaves with 1, 3..5, more than 15 triangles, and a tree that is one leaf."""
     st = _compare_room(tmp_path, thresh, lsn=1, p_rr=0.6, spp=3)
+    assert st["rays"] > 5000
+
+
+def test_leaf_of_more_than_255_triangles(tmp_path):
+    """k_mega3 keeps the best triangle's offset in its leaf in 8 bits; a scene with a bigger leaf (here: the whole 300-triangle
+    room is one leaf) renders with k_mega2 instead -- same result."""
+    st = _compare_room(tmp_path, 400, lsn=1, p_rr=0.6, spp=2, n_side=12)
+    assert st["rays"] > 5000
+
+
+@pytest.mark.parametrize("specular", [False, True])
+def test_rays_with_non_finite_operands_take_the_reference_arithmetic(tmp_path, specular):
+    """CRT_FLAG_FORCE_EXACT sends every ray of the FAST traversal down the path that rays with a zero / denormal direction
+    component take: reference box arithmetic (sign-selected planes, NaN-aware comparisons) on the reference topology, still
+    pruned and any-hit.  Nothing changes."""
+    st = _compare_room(tmp_path, 2, lsn=2, p_rr=0.7, spp=3, specular=specular, extra_flags=crt.FLAG_FORCE_EXACT)
     assert st["rays"] > 5000
 
 
