@@ -4,8 +4,10 @@
 // dot = p0 + (p1 + p2), normalized = v / sqrt(squaredNorm) with true division,
 // cross as in OrthoMethods.h.  Compiled with -ffp-contract=off.
 #include "crt_host.hpp"
+#include "crt_png.h"
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -163,10 +165,17 @@ const crt_scene_desc& Scene::flat()
     if (!bvh_) throw Error(CRT_ERR_INVALID_ARG, "Scene::flat before set_BVH");
     f_nodes_.clear(); f_tris_.clear(); f_light_tris_.clear(); f_mats_.clear(); f_lights_.clear();
     std::vector<Material> uniq;
+    std::map<std::array<uint32_t, 8>, int32_t> seen; // textured shapes carry one material per triangle: no linear search
     auto mat_id = [&](const Material& m) -> int32_t {
-        for (size_t i = 0; i < uniq.size(); i++)
-            if (uniq[i].same_as(m)) return (int32_t)i;
+        const Vec3 kd = m.get_kd(), ke = m.get_ke();
+        const float v[7] = {kd.x, kd.y, kd.z, ke.x, ke.y, ke.z, m.get_ns()};
+        std::array<uint32_t, 8> key;
+        std::memcpy(key.data(), v, sizeof(v));
+        key[7] = (uint32_t)m.get_mode();
+        auto it = seen.find(key);
+        if (it != seen.end() && uniq[it->second].same_as(m)) return it->second;
         uniq.push_back(m);
+        seen[key] = (int32_t)uniq.size() - 1;
         return (int32_t)uniq.size() - 1;
     };
     auto flat_tri = [&](const Triangle& t) {
@@ -232,6 +241,10 @@ void Loader::read_OBJ(const char* obj_path, const char* mtl_dir)
             Vec3 p;
             ls >> p.x >> p.y >> p.z;
             vertices_.push_back(p);
+        } else if (prefix == "vt") {
+            float u = 0.0f, v = 0.0f;
+            ls >> u >> v;
+            textures_.push_back(u); textures_.push_back(v);
         } else if (prefix == "vn") {
             n_normals_++; // values are never used downstream (Triangle.h:27-28), only their count matters
         } else if (prefix == "f") {
@@ -280,9 +293,24 @@ void Loader::read_OBJ(const char* obj_path, const char* mtl_dir)
             ls >> ns;
             for (size_t s : cur) shapes_[s].ns = ns;
         } else if (prefix == "map_Kd") {
-            for (size_t s : cur) shapes_[s].has_map_kd = true;
+            std::string name;
+            ls >> name;
+            for (size_t s : cur) { shapes_[s].has_map_kd = true; shapes_[s].map_kd = std::string(mtl_dir) + "/" + name; }
         } // Ks is parsed and discarded by the reference (Loader.h:45,107)
     }
+}
+
+const Loader::Texture& Loader::texture(const std::string& path) const
+{
+    auto it = tex_cache_.find(path);
+    if (it != tex_cache_.end()) return it->second;
+    crtpng::Image img;
+    const std::string err = crtpng::load(path, img);
+    if (!err.empty()) throw Error(err.rfind("cannot open", 0) == 0 ? CRT_ERR_IO : CRT_ERR_UNSUPPORTED, "map_Kd: " + err);
+    Texture t;
+    t.x = img.width; t.y = img.height; t.comp = img.comp;
+    t.px.swap(img.px);
+    return tex_cache_.emplace(path, std::move(t)).first->second;
 }
 
 // reference: include/Loader.h:40-124
@@ -292,7 +320,10 @@ void Loader::load_object(uint64_t index, std::vector<Triangle>& triangles, std::
     light_triangles.clear();
     if (index >= shapes_.size()) throw Error(CRT_ERR_INVALID_ARG, "Loader::load_object: shape index out of range");
     const Shape& s = shapes_[index];
-    if (s.has_map_kd) throw Error(CRT_ERR_UNSUPPORTED, "map_Kd textured materials are not supported yet (material " + s.material_id + ")");
+    // Loader.h:55-59: stbi_load(map_kd, &height, &width, &channel, 0) -- the reference receives the image's x in `height`
+    // and its y in `width`, and indexes with those names below; restated literally
+    const Texture* tex = s.has_map_kd ? &texture(s.map_kd) : nullptr;
+    const int width = tex ? tex->y : 0, height = tex ? tex->x : 0, channel = tex ? tex->comp : 0;
     Material m(mk(s.kd[0], s.kd[1], s.kd[2]), mk(s.ke[0], s.ke[1], s.ke[2]), s.ns, s.ns > 1 ? SPECULAR : DIFFUSE); // Loader.h:107
     for (size_t f = 0; f + 2 < s.faces.size(); f += 3) {
         uint64_t a = s.faces[f], b = s.faces[f + 1], c = s.faces[f + 2];
@@ -301,6 +332,27 @@ void Loader::load_object(uint64_t index, std::vector<Triangle>& triangles, std::
         // Loader.h:70-72 indexes normals[] with the vertex index: the reference reads out of bounds otherwise
         if (a >= n_normals_ || b >= n_normals_ || c >= n_normals_)
             throw Error(CRT_ERR_PARSE, "OBJ must carry one vn per v (reference Loader.h:70-72 indexes normals by vertex index)");
+        if (tex) {
+            // Loader.h:81-103: kd = mean of the texels at the three vertices; textures[] is indexed by the VERTEX index too
+            if (2 * a + 1 >= textures_.size() || 2 * b + 1 >= textures_.size() || 2 * c + 1 >= textures_.size())
+                throw Error(CRT_ERR_PARSE, "textured OBJ must carry one vt per v (reference Loader.h:81-83 indexes textures by vertex index)");
+            Vec3 k[3];
+            const uint64_t vi[3] = {a, b, c};
+            for (int q = 0; q < 3; q++) {
+                float intpart;
+                const float tu = textures_[2 * vi[q]], tv = textures_[2 * vi[q] + 1];
+                const int u = (int)(std::modf(std::modf(tu, &intpart) + 1, &intpart) * (width - 1));  // Loader.h:86,92,98
+                const int v = (int)(std::modf(std::modf(tv, &intpart) + 1, &intpart) * (height - 1)); // Loader.h:87,93,99
+                const long long offset = ((long long)v * width + u) * channel;                           // Loader.h:88
+                if (offset < 0 || (size_t)offset + 2 >= tex->px.size())
+                    throw Error(CRT_ERR_PARSE, "texture lookup outside the image (the reference indexes with width and height swapped, Loader.h:58): " + s.map_kd);
+                // Eigen::Vector3f(tex[o], tex[o+1], tex[o+2]) / 255.  (Loader.h:89; evaluated eagerly)
+                k[q] = mk((float)tex->px[offset] / 255.0f, (float)tex->px[offset + 1] / 255.0f, (float)tex->px[offset + 2] / 255.0f);
+            }
+            // kd = (kd_1 + kd_2 + kd_3) / 3  (Loader.h:103)
+            const Vec3 kd = mk(((k[0].x + k[1].x) + k[2].x) / 3.0f, ((k[0].y + k[1].y) + k[2].y) / 3.0f, ((k[0].z + k[1].z) + k[2].z) / 3.0f);
+            m = Material(kd, mk(s.ke[0], s.ke[1], s.ke[2]), s.ns, s.ns > 1 ? SPECULAR : DIFFUSE);
+        }
         Triangle t(vertices_[a], vertices_[b], vertices_[c], m);
         (m.has_emission() ? light_triangles : triangles).push_back(t); // Loader.h:119-122
     }

@@ -18,6 +18,7 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -174,10 +175,18 @@ private:
         float kd[3] = {0, 0, 0}, ke[3] = {0, 0, 0};
         float ns = 1.0f;
         bool has_map_kd = false;
+        std::string map_kd;          // mtl_dir + "/" + file name (OBJLoader.h:184-193)
     };
+    struct Texture {                 // what stbi_load returns (Loader.h:58): x, y, components, 8-bit samples
+        int x = 0, y = 0, comp = 0;
+        std::vector<uint8_t> px;
+    };
+    const Texture& texture(const std::string& path) const;
     std::vector<Shape> shapes_;
     std::vector<Vec3> vertices_;
+    std::vector<float> textures_;    // u, v per `vt` line (OBJLoader.h:88-93)
     size_t n_normals_ = 0;
+    mutable std::map<std::string, Texture> tex_cache_;
 };
 
 // reference: include/Camera.h:9-36; out is column-major

@@ -153,7 +153,7 @@ struct orc_scene {
 namespace {
 
 /* reference: include/OBJLoader.h:61-203 */
-bool parse_obj(const char* obj_path, const char* mtl_dir, std::vector<V3>& vertices, std::vector<V3>& normals,
+bool parse_obj(const char* obj_path, const char* mtl_dir, std::vector<V3>& vertices, std::vector<V3>& normals, std::vector<float>& textures,
                std::vector<Shape>& shapes, std::string& err)
 {
     std::ifstream obj(obj_path);
@@ -172,6 +172,10 @@ bool parse_obj(const char* obj_path, const char* mtl_dir, std::vector<V3>& verti
             V3 p{0, 0, 0};
             ls >> p.x >> p.y >> p.z;
             normals.push_back(p);
+        } else if (prefix == "vt") {                                         /* OBJLoader.h:88-93 */
+            float u = 0.0f, v = 0.0f;
+            ls >> u >> v;
+            textures.push_back(u); textures.push_back(v);
         } else if (prefix == "f") {
             std::vector<uint64_t> vi;
             std::string tok;
@@ -225,13 +229,43 @@ bool parse_obj(const char* obj_path, const char* mtl_dir, std::vector<V3>& verti
     return true;
 }
 
+/* What stbi_load(path, &x, &y, &comp, 0) returns for a map_Kd file (Loader.h:58).  stb_image is a vendored third-party
+ * decoder of the reference and is not restated: the test harness decodes the file with an independent decoder (PIL) and
+ * registers the samples here before the scene is loaded. */
+struct Texture { int x = 0, y = 0, comp = 0; std::vector<uint8_t> px; };
+std::map<std::string, Texture>& texture_registry()
+{
+    static std::map<std::string, Texture> r;
+    return r;
+}
+
+/* reference: include/Loader.h:86-89 -- texel under one vertex; `width` / `height` carry the reference's swapped meaning */
+bool texel(const Texture& t, int width, int height, int channel, float tu, float tv, V3& out)
+{
+    float intpart;
+    int u = static_cast<int>(std::modf(std::modf(tu, &intpart) + 1, &intpart) * (width - 1));
+    int v = static_cast<int>(std::modf(std::modf(tv, &intpart) + 1, &intpart) * (height - 1));
+    long long offset = ((long long)v * width + u) * channel;
+    if (offset < 0 || (size_t)offset + 2 >= t.px.size()) return false; /* the reference would read out of bounds */
+    out = v3((float)t.px[offset] / 255.0f, (float)t.px[offset + 1] / 255.0f, (float)t.px[offset + 2] / 255.0f); /* Vector3f(...) / 255. */
+    return true;
+}
+
 /* reference: include/Loader.h:40-124 */
-bool load_object(const Shape& s, const std::vector<V3>& vertices, const std::vector<V3>& normals,
+bool load_object(const Shape& s, const std::vector<V3>& vertices, const std::vector<V3>& normals, const std::vector<float>& textures,
                  std::vector<Triangle>& tris, std::vector<Triangle>& light_tris, std::string& err)
 {
     tris.clear();
     light_tris.clear();
-    if (s.has_map_kd) { err = "map_Kd textures are outside the oracle's scope (SURVEY 8(f) row 2)"; return false; }
+    const Texture* tex = nullptr;
+    int width = 0, height = 0, channel = 0;
+    if (s.has_map_kd) {
+        auto it = texture_registry().find(s.map_kd);
+        if (it == texture_registry().end()) { err = "map_Kd texture was not registered with the oracle (orc_register_texture): " + s.map_kd; return false; }
+        tex = &it->second;
+        /* Loader.h:58: stbi_load(map_kd.c_str(), &height, &width, &channel, 0) -- x lands in `height`, y in `width` */
+        height = tex->x; width = tex->y; channel = tex->comp;
+    }
     for (size_t i = 0; i < s.vs.size(); i++) {
         if (s.vs[i].size() < 3) { err = "face with fewer than 3 vertices"; return false; }
         uint64_t i1 = s.vs[i][0], i2 = s.vs[i][1], i3 = s.vs[i][2]; /* Loader.h:62-64: first three only */
@@ -241,6 +275,14 @@ bool load_object(const Shape& s, const std::vector<V3>& vertices, const std::vec
         if (i1 >= normals.size() || i2 >= normals.size() || i3 >= normals.size()) { err = "OBJ needs one vn per v (Loader.h:70-72)"; return false; }
         V3 kd = v3(s.kd[0], s.kd[1], s.kd[2]);
         V3 ke = v3(s.ke[0], s.ke[1], s.ke[2]);
+        if (tex) { /* Loader.h:79-105; textures[] is read with the VERTEX index (:81-83) */
+            if (2 * i1 + 1 >= textures.size() || 2 * i2 + 1 >= textures.size() || 2 * i3 + 1 >= textures.size()) { err = "textured OBJ needs one vt per v (Loader.h:81-83)"; return false; }
+            V3 k1, k2, k3;
+            if (!texel(*tex, width, height, channel, textures[2 * i1], textures[2 * i1 + 1], k1) ||
+                !texel(*tex, width, height, channel, textures[2 * i2], textures[2 * i2 + 1], k2) ||
+                !texel(*tex, width, height, channel, textures[2 * i3], textures[2 * i3 + 1], k3)) { err = "texture lookup outside the image (Loader.h:58 swaps width and height)"; return false; }
+            kd = ((k1 + k2) + k3) / 3.0f; /* Loader.h:103, the `auto` expressions of :89,:95,:101 evaluated eagerly */
+        }
         V3 zero = v3(0.0f, 0.0f, 0.0f); /* ks, ka are always zero: Loader.h:45,47,107 */
         Material m(kd, zero, zero, ke, s.ns, s.ns > 1 ? SPECULAR : DIFFUSE); /* Loader.h:107 */
         Triangle t(vertices[i1], vertices[i2], vertices[i3], m);
@@ -588,6 +630,15 @@ inline uint8_t tonemap1(float c) { return to_u8(255 * om_powf(clampf(0, 1, c), 0
 
 extern "C" {
 
+/* Registers the decoded samples of a map_Kd file (what stbi_load would return: x, y, components, 8-bit samples). */
+void orc_register_texture(const char* path, int x, int y, int comp, const uint8_t* px)
+{
+    Texture t;
+    t.x = x; t.y = y; t.comp = comp;
+    t.px.assign(px, px + (size_t)x * y * comp);
+    texture_registry()[path] = t;
+}
+
 orc_scene* orc_scene_new(void) { return new orc_scene(); }
 void orc_scene_free(orc_scene* s) { delete s; }
 
@@ -595,11 +646,12 @@ void orc_scene_free(orc_scene* s) { delete s; }
 int orc_scene_add_obj(orc_scene* sc, const char* obj_path, const char* mtl_dir)
 {
     std::vector<V3> vertices, normals;
+    std::vector<float> textures;
     std::vector<Shape> shapes;
-    if (!parse_obj(obj_path, mtl_dir, vertices, normals, shapes, sc->error)) { fprintf(stderr, "oracle: %s\n", sc->error.c_str()); return -1; }
+    if (!parse_obj(obj_path, mtl_dir, vertices, normals, textures, shapes, sc->error)) { fprintf(stderr, "oracle: %s\n", sc->error.c_str()); return -1; }
     std::vector<Triangle> tris, light_tris;
     for (size_t i = 0; i < shapes.size(); i++) {
-        if (!load_object(shapes[i], vertices, normals, tris, light_tris, sc->error)) { fprintf(stderr, "oracle: %s\n", sc->error.c_str()); return -2; }
+        if (!load_object(shapes[i], vertices, normals, textures, tris, light_tris, sc->error)) { fprintf(stderr, "oracle: %s\n", sc->error.c_str()); return -2; }
         if (!tris.empty()) { /* Scene::add_normal_obj, Scene.h:44-48 */
             Object o(tris, false);
             sc->triangles.insert(sc->triangles.end(), o.triangles.begin(), o.triangles.end());
@@ -787,6 +839,10 @@ int orc_vec_op(const char* op_, const float* in, float* out)
     if (op == "probe_chain") return put(k * cwise(a, b) * k2 * c.x);
     if (op == "div_unsigned7") return put(a / (float)7u);
     if (op == "centroid") return put(((a + b) + c) / 3.0f);
+    if (op == "texel_kd") { /* Loader.h:89-103: the nine inputs are 8-bit samples */
+        V3 k1 = v3(a.x / 255.0f, a.y / 255.0f, a.z / 255.0f), k2 = v3(b.x / 255.0f, b.y / 255.0f, b.z / 255.0f), k3 = v3(c.x / 255.0f, c.y / 255.0f, c.z / 255.0f);
+        return put(((k1 + k2) + k3) / 3.0f);
+    }
     if (op == "tri_normal") return put(normalized(cross(b - a, c - a)));
     if (op == "tri_area") { out[0] = norm(cross(b - a, c - a)) * 0.5f; return 1; }
     if (op == "cos_between") { out[0] = dot(normalized(a - b), c); return 1; }

@@ -77,6 +77,18 @@ int main() {
         { unsigned spp = 7; V r = a / spp; emit("div_unsigned7", in, f3(r)); }
         // reference: include/Triangle.h:26  (v1+v2+v3)/3
         { V r = (a + b + c) / 3; emit("centroid", in, f3(r)); }
+        // reference: include/Loader.h:89-103  kd = mean of three texels, each Vector3f(u8, u8, u8) / 255.  (evaluated eagerly)
+        {
+            unsigned char tx[9];
+            for (int q = 0; q < 9; q++) tx[q] = (unsigned char)(next_u32() & 255u);
+            unsigned char* t = opaque(&tx[0]);
+            V k1 = V(t[0], t[1], t[2]) / 255.;
+            V k2 = V(t[3], t[4], t[5]) / 255.;
+            V k3 = V(t[6], t[7], t[8]) / 255.;
+            V r = (k1 + k2 + k3) / 3;
+            std::vector<float> inb = {(float)t[0], (float)t[1], (float)t[2], (float)t[3], (float)t[4], (float)t[5], (float)t[6], (float)t[7], (float)t[8], 0.0f, 0.0f};
+            emit("texel_kd", inb, f3(r));
+        }
         // reference: include/Triangle.h:27,39  normal and area
         { V r = (b - a).cross(c - a).normalized(); emit("tri_normal", in, f3(r)); }
         { float r = (b - a).cross(c - a).norm() * 0.5f; emit("tri_area", in, {r}); }

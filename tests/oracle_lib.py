@@ -68,6 +68,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.orc_scene_new.restype = C.c_void_p
     L.orc_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.orc_register_texture.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_register_texture.restype = None
     L.orc_scene_build.argtypes = [C.c_void_p, C.c_uint32]
     L.orc_scene_free.argtypes = [C.c_void_p]
     for f in ("orc_scene_num_tris", "orc_scene_num_nodes", "orc_scene_num_lights", "orc_scene_num_objects"):
@@ -104,6 +106,52 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def stb_like_decode(path):
+    """Decodes an image with PIL into what stbi_load(path, &x, &y, &comp, 0) returns: (x, y, comp, uint8 samples).
+    An independent decoder: the product has its own PNG reader (csrc/crt_png.h)."""
+    from PIL import Image
+    img = Image.open(path)
+    if img.mode == "P":
+        img = img.convert("RGBA" if "transparency" in img.info else "RGB")
+    elif img.mode in ("1",):
+        img = img.convert("L")
+    elif img.mode in ("I;16", "I;16B", "I"):
+        a = np.asarray(img).astype(np.uint32)
+        img = Image.fromarray((a >> 8).astype(np.uint8), "L")  # stb keeps the high byte
+    elif img.mode == "L" and "transparency" in img.info:
+        key = img.info["transparency"]
+        a = np.asarray(img)
+        img = Image.fromarray(np.dstack([a, np.where(a == key, 0, 255).astype(np.uint8)]), "LA")
+    elif img.mode == "RGB" and "transparency" in img.info:
+        key = np.array(img.info["transparency"], dtype=np.uint8)
+        a = np.asarray(img)
+        alpha = np.where(np.all(a == key, axis=2), 0, 255).astype(np.uint8)
+        img = Image.fromarray(np.dstack([a, alpha]), "RGBA")
+    a = np.ascontiguousarray(np.asarray(img), dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a.shape[1], a.shape[0], a.shape[2], a
+
+
+def register_textures(obj_path, mtl_dir):
+    """Finds the map_Kd files of an OBJ's material library and hands their decoded samples to the oracle."""
+    mtl = None
+    with open(obj_path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) >= 2 and t[0] == "mtllib":
+                mtl = mtl_dir + "/" + t[1]
+    if not mtl or not os.path.exists(mtl):
+        return
+    with open(mtl) as f:
+        for line in f:
+            t = line.split()
+            if len(t) >= 2 and t[0] == "map_Kd":
+                path = mtl_dir + "/" + t[1]
+                x, y, comp, a = stb_like_decode(path)
+                lib().orc_register_texture(path.encode(), x, y, comp, a.ctypes.data_as(C.c_void_p))
+
+
 class OracleScene:
     """Scene loaded and BVH-built by the oracle's own restatement of the reference loader."""
 
@@ -111,6 +159,7 @@ class OracleScene:
         L = lib()
         self.h = L.orc_scene_new()
         for obj, mtl in obj_paths:
+            register_textures(obj, mtl)
             rc = L.orc_scene_add_obj(self.h, obj.encode(), mtl.encode())
             if rc != 0:
                 raise RuntimeError("oracle failed to load %s (%d)" % (obj, rc))
