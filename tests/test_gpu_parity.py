@@ -230,7 +230,7 @@ def test_errors_are_reported_not_printed(renders):
 # Edge cases the reference's data model allows: other leaf sizes (bvh_thresh_n), no / several NEE
 # samples, paths that run into the 64-vertex bounce cap, one-leaf trees, every pipeline variant.
 # ----------------------------------------------------------------------------------------------
-def _write_box_scene(d, n_side=6, specular=False):
+def _write_box_scene(d, n_side=6, specular=False, light=True):
     """A small closed room with an emissive quad and a tessellated floor (2 * n_side^2 + 12 triangles)."""
     import os
     v, f = [], []
@@ -251,7 +251,8 @@ def _write_box_scene(d, n_side=6, specular=False):
     quad((0, 0, 0), (S, 0, 0), (S, S, 0), (0, S, 0), "wall")             # front wall behind the camera, faces +z
     quad((0, 0, 0), (0, S, 0), (0, S, S), (0, 0, S), "wall")             # x = 0, faces +x
     quad((S, 0, 0), (S, 0, S), (S, S, S), (S, S, 0), "plate" if specular else "wall")  # x = S, faces -x
-    quad((4, S - 0.01, 4), (6, S - 0.01, 4), (6, S - 0.01, 6), (4, S - 0.01, 6), "light")
+    if light:
+        quad((4, S - 0.01, 4), (6, S - 0.01, 4), (6, S - 0.01, 6), (4, S - 0.01, 6), "light")
     with open(os.path.join(d, "room.mtl"), "w") as m:
         m.write("newmtl floor\nKd 0.7 0.6 0.5\nNs 1\nnewmtl wall\nKd 0.5 0.5 0.7\nNs 1\n"
                 "newmtl plate\nKd 0.1 0.2 0.3\nNs 500\nnewmtl light\nKe 30 25 20\nKd 0 0 0\nNs 1\n")
@@ -268,8 +269,8 @@ def _write_box_scene(d, n_side=6, specular=False):
     return os.path.join(d, "room.obj"), d
 
 
-def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, seed=3, n_side=6, extra_flags=0):
-    obj, mtl = _write_box_scene(str(tmp_path), n_side=n_side, specular=specular)
+def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, seed=3, n_side=6, extra_flags=0, light=True):
+    obj, mtl = _write_box_scene(str(tmp_path), n_side=n_side, specular=specular, light=light)
     scene = crt.Scene(w, h)
     scene.add_obj(obj, mtl)
     scene.set_BVH(thresh)
@@ -315,6 +316,12 @@ def test_rays_with_non_finite_operands_take_the_reference_arithmetic(tmp_path, s
     pruned and any-hit.  Nothing changes."""
     st = _compare_room(tmp_path, 2, lsn=2, p_rr=0.7, spp=3, specular=specular, extra_flags=crt.FLAG_FORCE_EXACT)
     assert st["rays"] > 5000
+
+
+def test_scene_without_emitters(tmp_path):
+    """No light object at all (DeviceLights with ln = 0): every vertex has zero next-event samples; the frame is black."""
+    st = _compare_room(tmp_path, 2, lsn=2, p_rr=0.7, spp=2, light=False)
+    assert st["shadow_rays"] == 0 and st["rays"] > 3000
 
 
 @pytest.mark.parametrize("lsn", [0, 1, 3])
