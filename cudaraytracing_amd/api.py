@@ -194,6 +194,26 @@ class Render:
         self.frame_buffer, self.mean_buffer, self.stats = rgb, mean, st.as_dict()
         return rgb
 
+    def run_view_range(self, eye_pos, inv_view_mat, fovY, sample_begin, sample_count, want_mean=True, width=None, height=None):
+        """Progressive rendering: adds samples [sample_begin, sample_begin + sample_count) of the spp samples per pixel to the
+        accumulator of the device scene; ranges go in ascending order from 0.  Returns the RGB8 frame once the range that ends
+        at spp has been rendered (bit-identical to run_view), None before."""
+        if not self._h:
+            raise RuntimeError("Render.run_view_range after free()")
+        cam = self._cam(eye_pos, inv_view_mat, fovY)
+        prm = self._params(flags=self.extra_flags, width=width, height=height)
+        w, h = prm.width, prm.height
+        last = sample_begin + sample_count == self.spp
+        rgb = np.zeros((h, w, 3), dtype=np.uint8) if last else None
+        mean = np.zeros((h, w, 3), dtype=np.float32) if (last and want_mean) else None
+        st = capi.Stats()
+        capi.check(capi.lib().crt_render_range(self._h, C.byref(cam), C.byref(prm), int(sample_begin), int(sample_count),
+                                               capi.ptr(rgb) if last else None, capi.ptr(mean), C.byref(st)), "crt_render_range")
+        self.stats = st.as_dict()
+        if last:
+            self.frame_buffer, self.mean_buffer = rgb, mean
+        return rgb
+
     def run_view_device(self, eye_pos, inv_view_mat, fovY, d_rgb_ptr, d_mean_ptr=None, stream=None, rank=0, world=1,
                         tiled=False, want_stats=True, width=None, height=None):
         """Enqueues a render whose outputs stay in device memory (raw device pointers)."""

@@ -2227,9 +2227,16 @@ void launch_trace_pass(crt_scene* sc, const TraceSetup& S, hipStream_t st)
     else launch_trace<0, false>(S.T, S.blocks, S.lds, st);
 }
 
-int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats)
+// Renders samples [s_begin, s_begin + s_count) of the prm->spp samples per pixel into the scene's accumulator
+// (temp_color += L_k / spp in sample order, Render.cuh:348); the range that ends at spp also tone-maps and writes the frame.
+int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, void* d_rgb, void* d_mean, hipStream_t st, crt_stats* stats,
+                uint32_t s_begin = 0, uint32_t s_count = 0xffffffffu)
 {
-    if (!sc || !cam || !prm || !d_rgb) return fail(CRT_ERR_INVALID_ARG, "crt_render: null argument");
+    if (!sc || !cam || !prm) return fail(CRT_ERR_INVALID_ARG, "crt_render: null argument");
+    if (s_count == 0xffffffffu) s_count = prm->spp > s_begin ? prm->spp - s_begin : 0;
+    if (s_count == 0 || (uint64_t)s_begin + s_count > prm->spp) return fail(CRT_ERR_INVALID_ARG, "crt_render: sample range outside [0, spp)");
+    const uint32_t s_end = s_begin + s_count;
+    if (!d_rgb && s_end == prm->spp) return fail(CRT_ERR_INVALID_ARG, "crt_render: null frame buffer");
     if (prm->width == 0 || prm->height == 0 || prm->spp == 0) return fail(CRT_ERR_INVALID_ARG, "crt_render: width, height and spp must be positive");
     if (prm->world == 0 || prm->rank >= prm->world) return fail(CRT_ERR_INVALID_ARG, "crt_render: need rank < world");
     if (prm->light_sample_n < 0 || prm->light_sample_n > 4096) return fail(CRT_ERR_INVALID_ARG, "crt_render: light_sample_n must be in [0, 4096]");
@@ -2242,7 +2249,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
     try {
         HIP_CHECK(hipSetDevice(sc->device));
         Shard sh = make_shard(prm->width, prm->height, prm->world);
-        uint32_t chunk = (uint32_t)std::min<uint64_t>(prm->spp, std::max<uint64_t>(1, kMaxChunkItems / sh.nslots));
+        uint32_t chunk = (uint32_t)std::min<uint64_t>(s_count, std::max<uint64_t>(1, kMaxChunkItems / sh.nslots));
         uint64_t cap = (uint64_t)chunk * sh.nslots;
         const uint32_t pool_log2 = std::min(26u, std::max(8u, env_u32("CRT_POOL_LOG2", 22)));
         const uint32_t pool_n = (uint32_t)std::min<uint64_t>((cap + 255) / 256 * 256, 1ull << pool_log2);
@@ -2338,8 +2345,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             if (timing) { e0 = sc->ev[0]; e1 = sc->ev[1]; e2 = sc->ev[2]; e3 = sc->ev[3]; HIP_CHECK(hipEventRecord(e0, st)); }
             double kernel_ms = 0.0;
             uint32_t launches = 0;
-            for (uint32_t s0 = 0; s0 < prm->spp; s0 += chunk) {
-                uint32_t ns = std::min(chunk, prm->spp - s0);
+            for (uint32_t s0 = s_begin; s0 < s_end; s0 += chunk) {
+                uint32_t ns = std::min(chunk, s_end - s0);
                 P.sample_begin = s0;
                 P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
@@ -2462,8 +2469,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         }
         const dim3 pool_grid((half_n + 255) / 256);
         const int evs_per_half = 2 * kMaxBatch + 1;
-        for (uint32_t s0 = 0; s0 < prm->spp; s0 += chunk) {
-            uint32_t ns = std::min(chunk, prm->spp - s0);
+        for (uint32_t s0 = s_begin; s0 < s_end; s0 += chunk) {
+            uint32_t ns = std::min(chunk, s_end - s0);
             P.sample_begin = s0;
             P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
             P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
@@ -2725,6 +2732,43 @@ int crt_render(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint
         HIP_CHECK(hipDeviceSynchronize()); // Render.cuh:440
         HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, npix * 3, hipMemcpyDeviceToHost)); // Render.cuh:464
         if (out_mean) HIP_CHECK(hipMemcpy(out_mean, d_mean.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        return CRT_OK;
+    } catch (const HipFail& f) {
+        return fail_hip(f);
+    }
+}
+
+int crt_render_range_device(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint32_t sample_begin, uint32_t sample_count,
+                            void* d_rgb, void* d_mean, void* stream, crt_stats* stats)
+{
+    if (sample_count == 0xffffffffu) return fail(CRT_ERR_INVALID_ARG, "crt_render_range: bad sample count");
+    return render_impl(sc, cam, prm, d_rgb, d_mean, (hipStream_t)stream, stats, sample_begin, sample_count);
+}
+
+int crt_render_range(crt_scene* sc, const crt_camera* cam, const crt_params* prm, uint32_t sample_begin, uint32_t sample_count,
+                     uint8_t* out_rgb, float* out_mean, crt_stats* stats)
+{
+    if (!sc || !prm) return fail(CRT_ERR_INVALID_ARG, "crt_render_range: null argument");
+    if (prm->world == 0 || prm->rank >= prm->world || prm->width == 0 || prm->height == 0) return fail(CRT_ERR_INVALID_ARG, "crt_render_range: bad shard or size");
+    if (sample_count == 0xffffffffu || sample_count == 0 || (uint64_t)sample_begin + sample_count > prm->spp)
+        return fail(CRT_ERR_INVALID_ARG, "crt_render_range: sample range outside [0, spp)");
+    const bool last = sample_begin + sample_count == prm->spp;
+    if (last && !out_rgb) return fail(CRT_ERR_INVALID_ARG, "crt_render_range: the range that ends at spp needs a frame buffer");
+    try {
+        HIP_CHECK(hipSetDevice(sc->device));
+        const bool tiled = (prm->flags & CRT_FLAG_TILED_OUTPUT) != 0;
+        uint64_t npix = tiled ? make_shard(prm->width, prm->height, prm->world).nslots : (uint64_t)prm->width * prm->height;
+        DevBuf<uint8_t> d_rgb;
+        DevBuf<float> d_mean;
+        if (last) d_rgb.alloc(npix * 3);
+        if (last && out_mean) d_mean.alloc(npix * 3);
+        int rc = render_impl(sc, cam, prm, last ? d_rgb.p : nullptr, last && out_mean ? d_mean.p : nullptr, nullptr, stats, sample_begin, sample_count);
+        if (rc != CRT_OK) return rc;
+        HIP_CHECK(hipDeviceSynchronize());
+        if (last) {
+            HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, npix * 3, hipMemcpyDeviceToHost));
+            if (out_mean) HIP_CHECK(hipMemcpy(out_mean, d_mean.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        }
         return CRT_OK;
     } catch (const HipFail& f) {
         return fail_hip(f);

@@ -173,6 +173,17 @@ int crt_render(crt_scene* scene, const crt_camera* cam, const crt_params* params
 int crt_render_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, void* d_rgb,
                       void* d_mean, void* hip_stream, crt_stats* stats);
 
+/* Progressive rendering (the reference re-renders all spp on every click, src/main.cu:368-377):
+ * renders samples [sample_begin, sample_begin + sample_count) of params->spp into the accumulator the scene handle
+ * owns (temp_color += L_k / spp, in sample order as Render.cuh:348).  Ranges must be submitted in ascending order
+ * starting at 0, with the same camera / params, and no other render call on the handle in between; the range that
+ * ends at spp tone-maps and writes out_rgb / out_mean -- bit-identical to one crt_render call.  For the other ranges
+ * out_rgb / out_mean are not written and may be NULL. */
+int crt_render_range(crt_scene* scene, const crt_camera* cam, const crt_params* params, uint32_t sample_begin,
+                     uint32_t sample_count, uint8_t* out_rgb, float* out_mean, crt_stats* stats);
+int crt_render_range_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, uint32_t sample_begin,
+                            uint32_t sample_count, void* d_rgb, void* d_mean, void* hip_stream, crt_stats* stats);
+
 /* Closest-hit query for n rays (device-side DeviceBVH::intersect,
  * DeviceBVH.cuh:128-170), host buffers. dirs are normalised as Ray's
  * constructor does (Ray.cuh:12-15). out_tri: BVH-order triangle index or -1. */

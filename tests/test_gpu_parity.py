@@ -356,3 +356,25 @@ def test_all_pipeline_variants_agree(renders, pipeline, monkeypatch):
         orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 128, 96, 2, t.P_RR, t.light_sample_n)
         assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
         assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
+
+
+@pytest.mark.parametrize("pipeline", ["2", "3", "4"])
+def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
+    """crt_render_range: samples rendered in ascending ranges accumulate in the reference's order (Render.cuh:348), so the
+    frame after the last range is the one-shot frame, bit for bit; ray counts add up."""
+    monkeypatch.setenv("CRT_PIPELINE", pipeline)
+    name = "veach-mis"
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.traversal = crt.TRAVERSAL_FAST
+    r.set_spp(7)
+    ref = r.run_view(eye, iv, fov, width=96, height=72).copy()
+    ref_mean, ref_rays = r.mean_buffer.copy(), r.stats["rays"]
+    rays, out = 0, None
+    for b, c in ((0, 2), (2, 1), (3, 4)):
+        out = r.run_view_range(eye, iv, fov, b, c, width=96, height=72)
+        rays += r.stats["rays"]
+        assert (out is None) == (b + c < 7)
+    assert np.array_equal(out, ref) and np.array_equal(util.bits(r.mean_buffer), util.bits(ref_mean)) and rays == ref_rays
+    with pytest.raises(crt.CrtError):
+        r.run_view_range(eye, iv, fov, 5, 3, width=96, height=72)   # beyond spp
