@@ -115,6 +115,7 @@ def main():
     t0 = time.perf_counter()
     kernel_ms, logic_ms, kernel_launches = [], [], []
     rays_local = 0
+    untraced_local = 0
     img = None
     for _ in range(args.steps):
         img, st = step()
@@ -122,6 +123,7 @@ def main():
         logic_ms.append(st["logic_ms"])
         kernel_launches.append(st["kernel_launches"])
         rays_local = st["rays"]
+        untraced_local = st.get("rays_untraced", 0)
     barrier()
     elapsed = time.perf_counter() - t0
     red_dev = torch.device("cpu") if one_device else device
@@ -165,6 +167,21 @@ def main():
                     "note": "achieved prices the reference's exhaustive visit set (SURVEY 8(d)); the kernel prunes and "
                             "walks a SAH tree over the same leaves, so frac can exceed 1; the scene is cache resident and the "
                             "kernel is bound by instruction issue / divergent 16 B loads, not by HBM (DESIGN.md)"}
+        # ---- the same frame with every next-event sample traced (CRT_FLAG_TRACE_ALL): the default path answers the samples whose
+        #      contribution is exactly zero without traversal (same frame bit for bit; they still count as rays of the reference) ----
+        all_traced = None
+        if world == 1:
+            render.set_spp(args.spp)
+            render.extra_flags = crt.FLAG_TRACE_ALL
+            step()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            _, st_all = step()
+            torch.cuda.synchronize(device)
+            dt_all = time.perf_counter() - c0
+            render.extra_flags = 0
+            all_traced = {"ms_per_step": round(dt_all * 1e3, 3), "mrays_per_sec": round(st_all["rays"] / dt_all / 1e6, 2),
+                          "kernel_ms": round(st_all["kernel_ms"], 3)}
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
         c2 = args.scene == "cornell-box" and (args.width, args.height, args.spp) == (800, 600, 512) and world == 1
         if c2 and os.path.exists(traffic_file):  # the PMC passes were collected on this exact workload
@@ -200,6 +217,11 @@ def main():
                        "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % world, "seed": args.seed},
             "frames_per_sec": round(1e3 / ms_per_step, 4),
             "rays_per_frame": int(rays_frame),
+            "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
+                               "equal to the oracle's count",
+            "rays_untraced_per_frame_rank0": int(untraced_local),
+            "mrays_traced_per_sec": round((rays_frame - (untraced_local if world == 1 else 0)) * args.steps / elapsed / 1e6, 2) if world == 1 else None,
+            "all_rays_traced": all_traced,
             "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
             "roofline": roofline,
         }

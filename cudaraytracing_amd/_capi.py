@@ -13,6 +13,7 @@ TRAVERSAL_REFERENCE = 1
 FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4
+FLAG_TRACE_ALL = 8
 TILE = 8
 
 
@@ -64,7 +65,7 @@ class Stats(C.Structure):
                 ("inner_pops", C.c_uint64), ("leaf_pops", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
                 ("stack_sum", C.c_uint64), ("stack_max", C.c_uint64), ("phase_cycles", C.c_uint64 * 24),
                 ("kernel_ms", C.c_float), ("logic_ms", C.c_float), ("total_ms", C.c_float),
-                ("kernel_launches", C.c_uint32)]
+                ("kernel_launches", C.c_uint32), ("rays_untraced", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "phase_cycles"}

@@ -218,7 +218,7 @@ class Render:
                         tiled=False, want_stats=True, width=None, height=None):
         """Enqueues a render whose outputs stay in device memory (raw device pointers)."""
         cam = self._cam(eye_pos, inv_view_mat, fovY)
-        flags = capi.FLAG_TILED_OUTPUT if (tiled or world > 1) else 0
+        flags = (capi.FLAG_TILED_OUTPUT if (tiled or world > 1) else 0) | self.extra_flags
         prm = self._params(rank=rank, world=world, flags=flags, width=width, height=height)
         st = capi.Stats()
         capi.check(capi.lib().crt_render_device(self._h, C.byref(cam), C.byref(prm), C.c_void_p(d_rgb_ptr),

@@ -50,7 +50,7 @@ namespace {
 // atomics per launch on ONE address serialise at the memory side (~12 ns each) and cost more
 // than the kernel itself.  The host sums the shards.
 enum { C_RAYS = 0, C_SHADOW, C_PROBE, C_INNER, C_LEAF, C_TESTS, C_HITS, C_PATHS, C_ALIVE, C_MAXSP, C_SUMSP, C_CYC_LOGIC, C_CYC_LEAF, C_CYC_INNER, C_CYC_OTHER,
-       C_DIAG /* CRT_DIAG_N more diagnostic slots (-DCRT_STAMPS builds) */, C_COUNT = C_DIAG + 20 };
+       C_DIAG /* CRT_DIAG_N more diagnostic slots (-DCRT_STAMPS builds) */, C_UNTRACED = C_DIAG + 20, C_COUNT };
 #define CNT_SHARDS 256
 #define CNT_STRIDE 40
 // The work-item cursor is sharded too: shard s hands out items [s*per, (s+1)*per); a wave
@@ -154,6 +154,7 @@ __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, un
 // ---------------------------------------------------------------- logic ----
 struct PathCounters {
     uint32_t rays, shadow, probe, paths;
+    uint32_t untraced; // next-event samples answered without traversal (contribution exactly zero); counted in rays / shadow too
 #ifdef CRT_STAMPS
     uint32_t sec[8]; // diagnostic build: wave passes through each logic section and lanes that needed it
     uint32_t sec_lanes[8];
@@ -1216,6 +1217,7 @@ struct Pool3Lds {
 struct MParams3 {
     MParams M;
     uint32_t force_exact;        // CRT_FLAG_FORCE_EXACT
+    uint32_t trace_all;          // CRT_FLAG_TRACE_ALL
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
@@ -1282,7 +1284,8 @@ __device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
 // that found a surface, or of a probe ray; enters the vertex if it is new; sets up the next next-event sample.
 // Returns PH3_NONE when a ray was emitted into nr, else the phase the path has to visit instead.
 template <int MODE>
-__device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
+__device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr,
+                                            PathCounters& cnt, const bool trace_all)
 {
     const DevScene& sc = P.sc;
     const Pool& pl = P.pool;
@@ -1386,9 +1389,23 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             return PH3_LB;
         }
     }
-    // next-event sample q of the current vertex
+    // next-event samples of the current vertex, from q on.  The reference traces every shadow ray and then adds
+    // Le (.) f_r * cos * cos' * ... to L_dir if it is unblocked (Render.cuh:272-284).  When that contribution is exactly
+    // zero (the surface or the light faces away: the cosines are clamped to 0; a black BSDF) the addition is the identity
+    // whatever the ray finds -- L_dir is never -0 -- so the FAST traversal answers the sample without tracing it.  It still
+    // counts as a ray of the reference (`rays`, `shadow_rays`); `rays_untraced` says how many there were.  A NaN contribution
+    // fails the comparison and is traced.  (CRT_TRAVERSAL_REFERENCE traces everything: its counters are the reference's visit set.)
     const float4 m0 = mat_row(tb, s.mat, 0);
-    setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
+    for (;;) {
+        setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
+        if (MODE == 1 || trace_all || !(s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f)) break;
+        cnt.rays++; cnt.shadow++; cnt.untraced++;
+        s.q++;
+        if (s.q == (uint32_t)(sc.n_lights * P.lsn)) { // that was the last sample of the vertex: on to the roulette
+            pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
+            return PH3_LB;
+        }
+    }
     pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
     pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, s.tl);
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
@@ -1779,7 +1796,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
             if (on) {
                 NewRay nr;
-                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr);
+                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr, cnt, M3.trace_all != 0);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
@@ -1811,13 +1828,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #undef POP3
 
     // ---- counters ----
-    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
+    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths), un = wave_sum(cnt.untraced);
     unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
     if (lane == 0 && (r | pa)) {
         atomicAdd(&cs[C_RAYS], (unsigned long long)r);
         atomicAdd(&cs[C_SHADOW], (unsigned long long)sh);
         atomicAdd(&cs[C_PROBE], (unsigned long long)pr);
         atomicAdd(&cs[C_PATHS], (unsigned long long)pa);
+        atomicAdd(&cs[C_UNTRACED], (unsigned long long)un);
     }
 #ifdef CRT_STAMPS
     if (lane == 0) {
@@ -2358,6 +2376,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     MParams3 M3;
                     M3.M = M;
                     M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
+                    M3.trace_all = (prm->flags & CRT_FLAG_TRACE_ALL) ? 1u : 0u;
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
@@ -2392,6 +2411,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 std::memset(stats, 0, sizeof(*stats));
                 stats->paths = counter_sum(C_PATHS); stats->rays = counter_sum(C_RAYS); stats->shadow_rays = counter_sum(C_SHADOW);
                 stats->probe_rays = counter_sum(C_PROBE);
+                stats->rays_untraced = counter_sum(C_UNTRACED);
                 stats->inner_pops = counter_sum(C_INNER); stats->leaf_pops = counter_sum(C_LEAF); stats->tri_tests = counter_sum(C_TESTS);
                 stats->hits = counter_sum(C_HITS);
                 stats->stack_sum = counter_sum(C_SUMSP);

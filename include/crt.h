@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 1
+#define CRT_ABI_VERSION 2
 
 typedef enum {
     CRT_OK = 0,
@@ -106,6 +106,8 @@ enum {
 enum {
     CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (slower counting kernels) */
     CRT_FLAG_TILED_OUTPUT = 2u,  /* write this rank's pixels in compact 8x8-tile order instead of row-major */
+    CRT_FLAG_TRACE_ALL = 8u,     /* CRT_TRAVERSAL_FAST traces every next-event sample, also those whose contribution is exactly
+                                    zero (crt_stats.rays_untraced stays 0); same frame, for measuring the traversal alone */
     CRT_FLAG_FORCE_EXACT = 4u    /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
                                     box arithmetic on the reference topology, still pruned / any-hit); results are unchanged */
 };
@@ -134,6 +136,8 @@ typedef struct {
     float logic_ms;              /* sum of the HIP-event times of the path-logic kernel (k_logic) launches */
     float total_ms;              /* HIP-event time of the whole device pipeline of this call */
     uint32_t kernel_launches;    /* number of k_trace launches */
+    uint64_t rays_untraced;      /* of `shadow_rays`: next-event samples whose contribution is exactly zero (clamped cosine, black
+                                    BSDF), answered without traversal by CRT_TRAVERSAL_FAST -- adding +0 cannot change L_dir */
 } crt_stats;
 
 /* ------------------------------------------------------------------------

@@ -378,3 +378,28 @@ def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
     assert np.array_equal(out, ref) and np.array_equal(util.bits(r.mean_buffer), util.bits(ref_mean)) and rays == ref_rays
     with pytest.raises(crt.CrtError):
         r.run_view_range(eye, iv, fov, 5, 3, width=96, height=72)   # beyond spp
+
+
+def test_zero_contribution_samples_are_answered_without_traversal(renders):
+    """FAST answers next-event samples whose contribution is exactly zero without tracing them (adding +0 cannot change L_dir):
+    same frame, same reference ray counts, with and without CRT_FLAG_TRACE_ALL; REFERENCE traces everything."""
+    for name in ("cornell-box", "veach-mis"):
+        t = util.task(name)
+        eye, iv, fov = util.camera(name)
+        r = renders[name]
+        r.set_spp(3)
+        out = {}
+        for key, trav, flags in (("fast", crt.TRAVERSAL_FAST, 0), ("all", crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL),
+                                 ("ref", crt.TRAVERSAL_REFERENCE, 0)):
+            r.traversal, r.extra_flags = trav, flags
+            rgb = r.run_view(eye, iv, fov, width=160, height=120)
+            out[key] = (rgb.copy(), r.mean_buffer.copy(), dict(r.stats))
+        r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
+        for key in ("all", "ref"):
+            assert np.array_equal(out[key][0], out["fast"][0]) and np.array_equal(util.bits(out[key][1]), util.bits(out["fast"][1]))
+            assert out[key][2]["rays"] == out["fast"][2]["rays"] and out[key][2]["shadow_rays"] == out["fast"][2]["shadow_rays"]
+            assert out[key][2]["rays_untraced"] == 0
+        un = out["fast"][2]["rays_untraced"]
+        assert 0 < un < out["fast"][2]["shadow_rays"]
+        orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 160, 120, 3, t.P_RR, t.light_sample_n)
+        assert np.array_equal(util.bits(out["fast"][1]), util.bits(omean)) and out["fast"][2]["rays"] == st["rays"]
