@@ -1217,7 +1217,6 @@ struct Pool3Lds {
 struct MParams3 {
     MParams M;
     uint32_t force_exact;        // CRT_FLAG_FORCE_EXACT
-    uint32_t trace_all;          // CRT_FLAG_TRACE_ALL
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
@@ -1546,7 +1545,9 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     t0 = t.x; t1 = t.y;
 }
 
-template <int MODE, bool STATS>
+// ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
+// are not mixed with it
+template <int MODE, bool STATS, bool ALL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mega3(const MParams3 M3)
 {
     __shared__ Pool3Lds S;
@@ -1796,7 +1797,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
             if (on) {
                 NewRay nr;
-                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr, cnt, M3.trace_all != 0);
+                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr, cnt, ALL);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
@@ -2376,11 +2377,12 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     MParams3 M3;
                     M3.M = M;
                     M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
-                    M3.trace_all = (prm->flags & CRT_FLAG_TRACE_ALL) ? 1u : 0u;
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
-                    if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
+                    if (mode_id == 0 && (prm->flags & CRT_FLAG_TRACE_ALL)) hipLaunchKernelGGL((k_mega3<0, false, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 1 && (prm->flags & CRT_FLAG_TRACE_ALL)) hipLaunchKernelGGL((k_mega3<0, true, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);

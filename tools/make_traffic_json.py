@@ -6,7 +6,7 @@ loads as 64 B, so reads are doubled)."""
 import json, sys
 summary, bench_line, out = sys.argv[1], sys.argv[2], sys.argv[3]
 d = json.load(open(summary))
-k = [n for n in d if n.startswith("k_mega3<0, false>")][0]
+k = [n for n in d if n.startswith("k_mega3<0, false, false>") or n.startswith("k_mega3<0, false>")][0]
 v = d[k]
 calls = 1  # tools/perf_probe.py --reps 1: one launch per pass
 fetch = v["FETCH_SIZE"] * 1024.0 / calls
