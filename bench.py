@@ -214,7 +214,11 @@ def main():
                        if args.scene == "cornell-box" else
                        "%s %dx%d spp=%d P_RR=%g light_sample_n=%d" % (args.scene, args.width, args.height, args.spp,
                                                                       float(task.P_RR), task.light_sample_n),
-                       "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % world, "seed": args.seed},
+                       "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % world, "seed": args.seed,
+                       "untraced_samples": "next-event samples whose contribution is exactly zero are answered without traversal "
+                                           "(frame bit-identical, still counted as rays of the reference): %.1f%% of the rays on rank 0; "
+                                           "`all_rays_traced` times the same frame with every one of them traced"
+                                           % (100.0 * untraced_local / max(1, rays_local))},
             "frames_per_sec": round(1e3 / ms_per_step, 4),
             "rays_per_frame": int(rays_frame),
             "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
