@@ -853,307 +853,13 @@ struct MParams {
     int32_t logic_min, leaf_min;
 };
 
-// ----------------------------------------------- megakernel, regrouped ----
-// k_mega keeps one ray per lane, so a wave-wide phase only ever serves the lanes that happen to be in
-// it (measured 42 % lane utilisation; a Monte-Carlo model of that scheduler says 48 % at best).  Here
-// every wave owns a private pool of POOL_P rays whose traversal state lives in LDS; each iteration
-// picks a phase and gathers up to 64 rays that are IN that phase with a ballot + prefix rank
-// (mbcnt), so the phase bodies run with (nearly) all lanes active.  A workgroup is one wave: the
-// pool needs no inter-wave synchronisation at all.
-//   LDS per wave: 3 x 16 B ray vectors + POOL_LV x 8 B stack entries per ray (1/direction and the pruning
-//   bound are recomputed every step: the kernel is latency bound, occupancy is worth more than ~40 VALU).  The phase of ray r is kept
-//   in a register of its "owner" lane (r mod 64); batches are formed and phase changes are sent back
-//   with ds_permute (lane-to-lane scatter through the LDS crossbar, no memory round trip).
-#ifndef POOL_P
-#define POOL_P 128
-#endif
 #ifndef POOL_LV
-#define POOL_LV 3
+#define POOL_LV 3 /* traversal stack levels kept in LDS per ray; deeper levels spill to global memory */
 #endif
-#define POOL_Q ((POOL_P + 63) / 64)
-#define PH_LOGIC 0
-#define PH_INNER 1
-#define PH_LEAF 2
-#define PH_DEAD 3
-
-struct PoolLds {
-    float4 r0[POOL_P];          // origin.xyz, t_limit
-    float4 r1[POOL_P];          // direction.xyz, best_t
-    int4 r3[POOL_P];            // best_tri, best_leaf, sp | any_hit << 16, current node ref
-    int2 stk[POOL_LV][POOL_P];  // traversal stack (node ref, t_enter); deeper levels spill to global memory
-};
-
-template <int MODE, bool STATS>
-__global__ __launch_bounds__(64) void k_mega2(const MParams M)
-{
-    __shared__ PoolLds S;
-    const LParams& P = M.P;
-    const DevScene& sc = M.sc;
-    const Pool& pl = P.pool;
-    const int lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * (uint32_t)POOL_P; // first global slot of this wave's pool
-    Tables<false> tb;
-    tb.mats = sc.mats; tb.lights = sc.lights;
-
-    PathCounters cnt;
-    cnt = PathCounters{};
-    TravCounters tc;
-    tc.inner = tc.leaf = tc.tests = tc.hits = 0;
-    uint32_t max_sp = 0, sum_sp = 0;
-
-#ifdef CRT_STAMPS
-    // diagnostic build only: shader-clock cycles, iterations and gathered rays per phase (never used by any output)
-    unsigned long long dg_cyc[4] = {0, 0, 0, 0};
-    unsigned dg_iter[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};
-    unsigned long long dg_prev = __builtin_amdgcn_s_memtime();
-#define CRT_STAMP2(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_cyc[i] += t_now - dg_prev; dg_prev = t_now; }
-#else
-#define CRT_STAMP2(i)
-#endif
-    uint32_t ph[POOL_Q]; // phase of the rays this lane owns: lane, lane + 64, ...
-#pragma unroll
-    for (int q = 0; q < POOL_Q; q++) {
-        const int i = lane + 64 * q;
-        ph[q] = (i < POOL_P && base + i < pl.n) ? PH_LOGIC : PH_DEAD;
-        if (i < POOL_P) {
-            S.r1[i] = make_float4(0.0f, 0.0f, 0.0f, FLT_MAX);
-            S.r3[i] = make_int4(-1, -1, 0, 0);
-            S.r0[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-    }
-
-    for (;;) {
-        // ---- census over the owners' phase registers ----
-        int n_logic = 0, n_inner = 0, n_leaf = 0;
-#pragma unroll
-        for (int q = 0; q < POOL_Q; q++) {
-            n_logic += __popcll(__ballot(ph[q] == PH_LOGIC));
-            n_inner += __popcll(__ballot(ph[q] == PH_INNER));
-            n_leaf += __popcll(__ballot(ph[q] == PH_LEAF));
-        }
-        if (n_logic + n_inner + n_leaf == 0) break; // every ray of the pool is dead
-        CRT_STAMP2(3)
-        uint32_t act;
-        if (n_logic >= M.logic_min || (n_inner == 0 && n_leaf == 0)) act = PH_LOGIC;
-        else if (n_leaf >= M.leaf_min || n_inner == 0) act = PH_LEAF;
-        else act = PH_INNER;
-        // ---- gather: the first 64 rays in phase `act`, in pool order: every owner of such a ray sends its
-        //      id to lane `rank` (ballot + prefix popcount) with a ds_permute scatter ----
-        int taken = 0;
-        uint32_t got = 0;
-        int sent_to[POOL_Q]; // where this lane's ray of slot q went (-1: not gathered)
-        const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int q = 0; q < POOL_Q; q++) {
-            const bool mine = ph[q] == act;
-            const unsigned long long m = __ballot(mine);
-            const int rank = taken + (int)__popcll(m & below);
-            const bool send = mine && rank < 64;
-            const unsigned long long sm = __ballot(send);
-            const int k = (int)__popcll(sm);
-            // ds_permute: EVERY lane writes one destination, so the lanes that have nothing to send must cover the
-            // destinations outside the senders' contiguous rank range [taken, taken + k) exactly once, with a 0
-            const int r2 = lane - (int)__popcll(sm & below); // rank among the non-senders
-            const int dst = send ? rank : (r2 < taken ? r2 : r2 + k);
-            got |= (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, send ? (lane + 64 * q + 1) : 0);
-            sent_to[q] = send ? rank : -1;
-            taken += (int)__popcll(m);
-        }
-        const int n = min(taken, 64);
-        const bool on = lane < n;
-#ifdef CRT_STAMPS
-        dg_iter[act]++; dg_lanes[act] += (unsigned)n;
-#endif
-        const uint32_t id = on ? got - 1u : 0u;
-        const uint32_t g = base + id;
-        uint32_t nph = PH_DEAD; // new phase of the ray this lane processes
-
-        if (act == PH_LOGIC) {
-            if (on) {
-                float4 la = pl.la[g], cc = pl.cc[g], vx = pl.vx[g], vn = pl.vn[g];
-                uint4 idv = pl.id[g];
-                const float4 q0 = S.r0[id], q1 = S.r1[id];
-                const int4 q3 = S.r3[id];
-                uint32_t st = __float_as_uint(la.w);
-                const uint32_t stage = (st >> 8) & 15u;
-                Lane s;
-                s.depth = st & 255u; s.stage = stage; s.q = st >> 16;
-                s.Ld = f3(la.x, la.y, la.z);
-                s.kind = RAY_NONE;
-                s.c = f3(cc.x, cc.y, cc.z);
-                s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
-                s.ro = f3(q0.x, q0.y, q0.z); s.tl = q0.w;
-                s.rd = f3(q1.x, q1.y, q1.z);
-                s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
-                s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
-                if (STATS && stage != ST_NEW) {
-                    if (q3.x >= 0) tc.hits++;
-                }
-                const bool emitted = logic_advance(P, tb, g, s, stage, q1.w, q3.x, cnt);
-                if (emitted) {
-                    st = s.depth | (s.stage << 8) | (s.q << 16);
-                    pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(st));
-                    if (s.stage == ST_SHADOW) pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, 0.0f);
-                    if (stage != ST_SHADOW) {
-                        pl.vx[g] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
-                        pl.vn[g] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
-                    }
-                    TravLane L;
-                    L.r.o = s.ro; L.r.d = s.rd;
-                    const int ts = trav_begin<MODE>(sc, L, s.kind, s.tl);
-                    S.r0[id] = make_float4(L.r.o.x, L.r.o.y, L.r.o.z, L.t_limit);
-                    S.r1[id] = make_float4(L.r.d.x, L.r.d.y, L.r.d.z, L.best_t);
-                    S.r3[id] = make_int4(L.best_tri, L.best_leaf, L.any_hit ? 0x10000 : 0, L.ref);
-                    nph = ts == TR_IDLE ? PH_LOGIC : (ts == TR_INNER ? PH_INNER : PH_LEAF);
-                }
-            }
-        } else if (on) {
-            // ---- traversal step for the gathered rays ----
-            const float4 q0 = S.r0[id], q1 = S.r1[id];
-            int4 q3 = S.r3[id];
-            RayT r;
-            r.o = f3(q0.x, q0.y, q0.z); r.d = f3(q1.x, q1.y, q1.z);
-            r.inv = f3(1 / r.d.x, 1 / r.d.y, 1 / r.d.z); // Ray.cuh:14 (same bits as trav_begin computed)
-            const float t_limit = q0.w;
-            float best_t = q1.w;
-            int sp = q3.z & 0xffff;
-            const bool any_hit = (q3.z & 0x10000) != 0;
-            // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
-            float bound = any_hit ? prune_bound(t_limit) : (MODE == 0 && q3.x >= 0 ? prune_bound(best_t) : FLT_MAX);
-            int ref = q3.w;
-            bool done = false, need_pop = false;
-            if (act == PH_LEAF) {
-                uint32_t code = (uint32_t)~ref;
-                const int it = (int)(code >> 4);
-                int nt = (int)(code & 15u);
-                if (nt == 0) nt = sc.leaf_count[it];
-                const bool two = nt > 1;
-                float t0, t1;
-                const bool a0 = tri_test(sc, it, r, t0);
-                const bool a1 = tri_test(sc, two ? it + 1 : it, r, t1) && two;
-                if (STATS) { tc.leaf++; tc.tests += two ? 2u : 1u; }
-                if (any_hit) {
-                    const bool b0 = a0 && (t_limit - t0 > CRT_EPSILON);
-                    const bool b1 = a1 && (t_limit - t1 > CRT_EPSILON);
-                    done = b0 || b1;
-                    best_t = b0 ? t0 : (b1 ? t1 : best_t);
-                    q3.x = b0 ? it : (b1 ? it + 1 : q3.x);
-                } else {
-                    const bool w0 = a0 && (t0 < best_t || (t0 == best_t && it > q3.y));
-                    best_t = w0 ? t0 : best_t; q3.x = w0 ? it : q3.x; q3.y = w0 ? it : q3.y;
-                    const bool w1 = a1 && (t1 < best_t || (t1 == best_t && it > q3.y));
-                    best_t = w1 ? t1 : best_t; q3.x = w1 ? it + 1 : q3.x; q3.y = w1 ? it : q3.y;
-                    if (MODE == 0) bound = (w0 || w1) ? prune_bound(best_t) : bound;
-                }
-                for (int i = it + 2; i < it + nt && !done; i++) { // only with bvh_thresh_n > 2
-                    if (STATS) tc.tests++;
-                    float t;
-                    if (tri_test(sc, i, r, t)) {
-                        if (any_hit) {
-                            if (t_limit - t > CRT_EPSILON) { best_t = t; q3.x = i; done = true; }
-                        } else if (t < best_t || (t == best_t && it > q3.y)) {
-                            best_t = t; q3.x = i; q3.y = it;
-                            if (MODE == 0) bound = prune_bound(t);
-                        }
-                    }
-                }
-                S.r1[id].w = best_t;
-                need_pop = !done;
-            } else {
-                if (STATS) tc.inner++;
-                const float4* nd = sc.nodes + (size_t)ref * 4;
-                float4 a = nd[0], b = nd[1], c = nd[2], d = nd[3];
-                const bool nx = r.d.x < 0, ny = r.d.y < 0, nz = r.d.z < 0;
-                float tl, tr;
-                bool hl = slab_test(a, b, r, nx, ny, nz, tl);
-                bool hr = slab_test(c, d, r, nx, ny, nz, tr);
-                const int lref = __float_as_int(a.w), rref = __float_as_int(b.w);
-                bool left_first;
-                if (MODE == 1) {
-                    left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
-                } else {
-                    hl = hl && !(tl > bound);
-                    hr = hr && !(tr > bound);
-                    left_first = tl <= tr;
-                }
-                const bool both = hl && hr, any = hl || hr;
-                const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
-                if (both) {
-                    const int2 e = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
-                    if (sp < POOL_LV) S.stk[sp][id] = e;
-                    else M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = e;
-                    sp++;
-                    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-                }
-                ref = any ? near_ref : ref;
-                need_pop = !any;
-            }
-            // pop until a node that is still within the pruning bound
-            while (need_pop) {
-                if (sp == 0) { done = true; break; }
-                sp--;
-                int2 e;
-                if (sp < POOL_LV) e = S.stk[sp][id];
-                else e = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
-                ref = e.x;
-                if (MODE == 0 && __int_as_float(e.y) > bound) continue;
-                need_pop = false;
-            }
-            q3.z = sp | (any_hit ? 0x10000 : 0);
-            q3.w = ref;
-            S.r3[id] = q3;
-            nph = done ? PH_LOGIC : (ref >= 0 ? PH_INNER : PH_LEAF);
-        }
-        // ---- the owners fetch the new phase of their gathered rays from the lane that processed them ----
-#pragma unroll
-        for (int q = 0; q < POOL_Q; q++) {
-            const uint32_t back = (uint32_t)__builtin_amdgcn_ds_bpermute((sent_to[q] >= 0 ? sent_to[q] : lane) << 2, (int)nph);
-            if (sent_to[q] >= 0) ph[q] = back;
-        }
-        CRT_STAMP2(act)
-    }
-#ifdef CRT_STAMPS
-    if (lane == 0) {
-        unsigned long long* cs2 = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
-        atomicAdd(&cs2[C_CYC_LOGIC], dg_cyc[PH_LOGIC]); atomicAdd(&cs2[C_CYC_LEAF], dg_cyc[PH_LEAF]);
-        atomicAdd(&cs2[C_CYC_INNER], dg_cyc[PH_INNER]); atomicAdd(&cs2[C_CYC_OTHER], dg_cyc[3]);
-        for (int i = 0; i < 3; i++) { atomicAdd(&cs2[C_DIAG + i], (unsigned long long)dg_iter[i]); atomicAdd(&cs2[C_DIAG + 3 + i], (unsigned long long)dg_lanes[i]); }
-        for (int i = 0; i < 8; i++) atomicAdd(&cs2[C_DIAG + 6 + i], (unsigned long long)cnt.sec[i]);
-    }
-    for (int i = 0; i < 6; i++) {
-        // lanes per logic section (sections 0..5; 6 and 7 follow from the rest)
-        if (lane == 0) atomicAdd(&M.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + C_DIAG + 14 + i], (unsigned long long)cnt.sec_lanes[i == 5 ? 7 : i]);
-    }
-#endif
-
-    // ---- counters ----
-    uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths);
-    unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
-    if (lane == 0 && (r | pa)) {
-        atomicAdd(&cs[C_RAYS], (unsigned long long)r);
-        atomicAdd(&cs[C_SHADOW], (unsigned long long)sh);
-        atomicAdd(&cs[C_PROBE], (unsigned long long)pr);
-        atomicAdd(&cs[C_PATHS], (unsigned long long)pa);
-    }
-    if (STATS) {
-        uint32_t a = wave_sum(tc.inner), b = wave_sum(tc.leaf), c = wave_sum(tc.tests), d = wave_sum(tc.hits);
-        uint32_t ss = wave_sum(sum_sp);
-        uint32_t ms = max_sp;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ms = max(ms, (uint32_t)__shfl_xor((int)ms, o, 64));
-        if (lane == 0) {
-            atomicAdd(&cs[C_INNER], (unsigned long long)a);
-            atomicAdd(&cs[C_LEAF], (unsigned long long)b);
-            atomicAdd(&cs[C_TESTS], (unsigned long long)c);
-            atomicAdd(&cs[C_HITS], (unsigned long long)d);
-            atomicAdd(&cs[C_SUMSP], (unsigned long long)ss);
-            atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
-        }
-    }
-}
 
 // --------------------------------------- megakernel, queued sub-phases ----
-// k_mega2 spends 22 % of its cycles in a logic phase whose sections each serve 20-60 % of the gathered
+// Its predecessor k_mega2 (wave-private LDS pool, rays regrouped by phase with ballot / prefix rank / ds_permute, one logic
+// phase; 223 ms on C2, removed) spent 22 % of its cycles in a logic phase whose sections each serve 20-60 % of the gathered
 // lanes, 11 % in the census / permute gather, and its inner-node batches average 47 of 64 lanes
 // (-DCRT_STAMPS counters).  Sensitivity probes (tools/diag_sens.sh) show the kernel is bound by vector
 // instruction ISSUE: every wave instruction added to the inner step costs ~5 SIMD cycles, additively, so
@@ -1187,13 +893,13 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
 #define PH3_NONE 7
 #define ST_FIN 5   /* path complete, backward recursion pending (q bit 0: the deepest vertex is an emitter) */
 #define ST_NEED 6  /* vertex entered with zero next-event samples: straight to roulette */
-// word D of the ray record: traversal stack depth (bits 0-7), best triangle - first triangle of its leaf (bits 8-15), flags
-#define RF_ANYHIT 0x10000   /* traversal stops at the first accepted hit closer than the light */
-#define RF_SHADOW 0x20000   /* the ray is a next-event sample ... */
-#define RF_LAST 0x40000     /* ... and the last one of its vertex */
-#define RF_PROBE 0x80000    /* SPECULAR emitter probe */
-#define RF_EXACT 0x100000   /* reference box arithmetic (non-finite operands) */
-#define RF_HASHIT 0x200000  /* closest-hit ray: a hit is recorded (T = its distance) */
+// word D of the ray record: traversal stack depth (bits 0-7), best triangle - first triangle of its leaf (bits 8-23), flags
+#define RF_ANYHIT 0x1000000u   /* traversal stops at the first accepted hit closer than the light */
+#define RF_SHADOW 0x2000000u   /* the ray is a next-event sample ... */
+#define RF_LAST 0x4000000u     /* ... and the last one of its vertex */
+#define RF_PROBE 0x8000000u    /* SPECULAR emitter probe */
+#define RF_EXACT 0x10000000u   /* reference box arithmetic (non-finite operands) */
+#define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
 #ifndef POOL3_P
 #define POOL3_P 126         /* 126 x 76 B + rings = 10 216 B: 16 waves per CU */
 #endif
@@ -1201,7 +907,7 @@ __global__ __launch_bounds__(64) void k_mega2(const MParams M)
 #if POOL3_P > POOL3_QCAP || POOL3_QCAP > 256
 #error "POOL3_QCAP must be a power of two in [POOL3_P, 256]"
 #endif
-#define CRT_MEGA3_MAX_LEAF 255 /* best-triangle offset inside its leaf is kept in 8 bits */
+#define CRT_MEGA3_MAX_LEAF 65535 /* best-triangle offset inside its leaf is kept in 16 bits */
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -1734,7 +1440,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 int tri = __float_as_int(qb.w);
                 int sp = (int)(qd & 0xffu);
                 const bool any_hit = (qd & RF_ANYHIT) != 0;
-                int best_leaf = tri - (int)((qd >> 8) & 0xffu); // first triangle of the leaf that holds the best hit (-1 - 0 if none)
+                int best_leaf = tri - (int)((qd >> 8) & 0xffffu); // first triangle of the leaf that holds the best hit (-1 - 0 if none)
                 bool done = false;
                 uint32_t rec = (uint32_t)~ref;
                 int it0 = 0, left = 1;
@@ -1781,7 +1487,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     if (MODE == 0 && __int_as_float(en.y) > bound) continue;
                     need_pop = false;
                 }
-                qd = (qd & 0xffff0000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xff00u) | (uint32_t)sp;
+                qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
                 S.C[id].w = __int_as_float(ref);
@@ -2295,27 +2001,20 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         unsigned long long alive_seen = 0;
 
         uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
-        if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 3; // k_mega3 keeps the best triangle's offset in its leaf in 8 bits
-        if (pipeline == 3 || pipeline == 4) {
+        if (pipeline != 2) pipeline = 4;
+        if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 2; // k_mega3 keeps the best triangle's offset in its leaf in 16 bits
+        if (pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
             const int lds_cap = POOL_LV;
             const int mode_id = (reference ? 2 : 0) + (want_stats ? 1 : 0);
-            const bool queued = pipeline == 4;
-            const uint32_t pool_p = queued ? (uint32_t)POOL3_P : (uint32_t)POOL_P;
+            const uint32_t pool_p = (uint32_t)POOL3_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
             int per_cu = 1;
             uint32_t blocks, lanes;
             {
                 // one wave per workgroup, pool_p rays per wave
-                auto q2 = [&](int* n) {
-                    hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<0, false>, 64, 0)
-                                 : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<0, true>, 64, 0)
-                                 : mode_id == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<1, false>, 64, 0)
-                                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega2<1, true>, 64, 0);
-                    if (e != hipSuccess || *n < 1) *n = 1;
-                };
                 auto q3 = [&](int* n) {
                     hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, false>, 64, 0)
                                  : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, true>, 64, 0)
@@ -2323,7 +2022,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, true>, 64, 0);
                     if (e != hipSuccess || *n < 1) *n = 1;
                 };
-                if (queued) q3(&per_cu); else q2(&per_cu);
+                q3(&per_cu);
                 per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
                 blocks = std::min<uint32_t>((uint32_t)((cap + pool_p - 1) / pool_p), (uint32_t)(sc->n_cus * per_cu));
                 lanes = blocks * pool_p; // pool slots
@@ -2351,8 +2050,6 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
             P.L = sc->L.p; P.counters = sc->counters.p; P.item_next = sc->item_next.p; P.n_mats = sc->n_mats;
             M.sc = sc->dev; M.counters = sc->counters.p; M.spill = sc->spill[0].p; M.spill_stride = lanes; M.stack_cap = lds_cap;
-            M.logic_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LOGIC_MIN", 64));
-            M.leaf_min = (int32_t)std::min<uint32_t>(64, env_u32("CRT_LEAF_MIN", 48));
             AParams A;
             std::memset(&A, 0, sizeof(A));
             A.width = prm->width; A.height = prm->height; A.spp = prm->spp;
@@ -2371,9 +2068,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
                 M.P = P;
                 HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
-                if (!queued) hipLaunchKernelGGL(k_pool_init, dim3((lanes + 255) / 256), dim3(256), 0, st, pool);
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
-                if (queued) {
+                {
                     MParams3 M3;
                     M3.M = M;
                     M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
@@ -2386,11 +2082,6 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
-                } else {
-                    if (mode_id == 0) hipLaunchKernelGGL((k_mega2<0, false>), dim3(blocks), dim3(64), 0, st, M);
-                    else if (mode_id == 1) hipLaunchKernelGGL((k_mega2<0, true>), dim3(blocks), dim3(64), 0, st, M);
-                    else if (mode_id == 2) hipLaunchKernelGGL((k_mega2<1, false>), dim3(blocks), dim3(64), 0, st, M);
-                    else hipLaunchKernelGGL((k_mega2<1, true>), dim3(blocks), dim3(64), 0, st, M);
                 }
                 HIP_CHECK(hipGetLastError());
                 if (timing) {

@@ -302,9 +302,8 @@ def test_other_leaf_sizes(tmp_path, thresh):
     assert st["rays"] > 5000
 
 
-def test_leaf_of_more_than_255_triangles(tmp_path):
-    """k_mega3 keeps the best triangle's offset in its leaf in 8 bits; a scene with a bigger leaf (here: the whole 300-triangle
-    room is one leaf) renders with k_mega2 instead -- same result."""
+def test_leaf_of_300_triangles(tmp_path):
+    """The whole 300-triangle room as ONE leaf (150 triangle-pair records, best-triangle offsets beyond 8 bits)."""
     st = _compare_room(tmp_path, 400, lsn=1, p_rr=0.6, spp=2, n_side=12)
     assert st["rays"] > 5000
 
@@ -342,9 +341,9 @@ def test_specular_probe_rays(tmp_path):
     assert st["probe_rays"] > 0
 
 
-@pytest.mark.parametrize("pipeline", ["2", "3", "4"])
+@pytest.mark.parametrize("pipeline", ["2", "4"])
 def test_all_pipeline_variants_agree(renders, pipeline, monkeypatch):
-    """CRT_PIPELINE selects k_mega3 (4, default), k_mega2 (3) or the wavefront rounds (2)."""
+    """CRT_PIPELINE selects k_mega3 (4, default) or the wavefront rounds (2: k_logic + k_trace, scalar box / triangle tests)."""
     monkeypatch.setenv("CRT_PIPELINE", pipeline)
     for name in ("cornell-box", "veach-mis"):
         t = util.task(name)
@@ -358,7 +357,7 @@ def test_all_pipeline_variants_agree(renders, pipeline, monkeypatch):
         assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
 
 
-@pytest.mark.parametrize("pipeline", ["2", "3", "4"])
+@pytest.mark.parametrize("pipeline", ["2", "4"])
 def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
     """crt_render_range: samples rendered in ascending ranges accumulate in the reference's order (Render.cuh:348), so the
     frame after the last range is the one-shot frame, bit for bit; ray counts add up."""
