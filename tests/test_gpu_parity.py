@@ -402,3 +402,28 @@ def test_zero_contribution_samples_are_answered_without_traversal(renders):
         assert 0 < un < out["fast"][2]["shadow_rays"]
         orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 160, 120, 3, t.P_RR, t.light_sample_n)
         assert np.array_equal(util.bits(out["fast"][1]), util.bits(omean)) and out["fast"][2]["rays"] == st["rays"]
+
+
+def test_baseline_size_frame_properties(renders):
+    """BASELINE configuration C2 at full size (cornell-box 800x600 spp 512, 1.1 G rays): the default path, the path with every
+    sample traced, the exhaustive REFERENCE traversal and a render split into progressive ranges give the same frame bit for
+    bit and the same ray counts."""
+    name = "cornell-box"
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.set_spp(512)
+    r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
+    rgb = r.run_view(eye, iv, fov).copy()
+    mean, st = r.mean_buffer.copy(), dict(r.stats)
+    assert st["paths"] == 800 * 600 * 512 and st["rays"] > 10 ** 9 and 0 < st["rays_untraced"] < st["shadow_rays"]
+    for trav, flags in ((crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0)):
+        r.traversal, r.extra_flags = trav, flags
+        rgb2 = r.run_view(eye, iv, fov)
+        assert np.array_equal(rgb2, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean))
+        assert r.stats["rays"] == st["rays"] and r.stats["shadow_rays"] == st["shadow_rays"] and r.stats["rays_untraced"] == 0
+    r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
+    out = None
+    for b, c in ((0, 100), (100, 156), (256, 256)):
+        out = r.run_view_range(eye, iv, fov, b, c)
+    assert np.array_equal(out, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean))
+    assert np.isfinite(mean).all() and mean.min() >= 0.0
