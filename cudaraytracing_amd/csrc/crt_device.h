@@ -53,6 +53,10 @@ struct DevScene {
                              //   (e2.x a, e2.x b, e2.y a, e2.y b) (e2.z a, e2.z b, bits(index of a), bits(triangles of the leaf from a on))
                              // a leaf of n triangles owns ceil(n / 2) consecutive records
     int32_t root3_fast, root3_exact;
+    const float4* nodes4;    // the SAH tree collapsed to 4 children per node, 8 x float4 per node: children (0,1) as in nodes3
+                             // [0..2], children (2,3) [3..5], [6] = bits(ref 0..3) (>= 0: nodes4 index, < 0: leaf as in nodes3),
+                             // [7] padding; an empty slot has NaN boxes (no comparison of the slab test passes)
+    int32_t root4;           // root of the 4-wide tree (a leaf ref if the scene is a single leaf)
     const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
 };
 

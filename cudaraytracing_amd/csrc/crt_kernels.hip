@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -958,7 +959,8 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX; // a finite 1/d has a finite d
     const bool finite = finite_inv && absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX;
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
-    const int ref = (MODE == 0 && finite_inv && !force_exact) ? sc.root3_fast : sc.root3_exact;
+    // (MODE 0: a ray that is not RF_EXACT walks the 4-wide tree; finite implies finite_inv)
+    const int ref = (MODE == 0 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
     bool answered = false;
     float T = FLT_MAX;
     if (MODE == 0 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
@@ -1251,6 +1253,101 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     t0 = t.x; t1 = t.y;
 }
 
+// Pops the traversal stack of ray `id` until a node that is still within the pruning bound; returns true when the stack ran
+// empty (the ray is finished).  The LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform
+// branch: a per-lane choice between the two address spaces would compile to a flat load that waits on both memory pipes.
+template <int MODE, class LDS>
+__device__ __forceinline__ bool stack_pop(LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const float bound, int& sp, int& ref)
+{
+    for (;;) {
+        if (sp == 0) return true;
+        sp--;
+        int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
+        if (__ballot(sp >= POOL_LV)) {
+            if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
+        }
+        ref = en.x;
+        if (MODE == 0 && __int_as_float(en.y) > bound) continue;
+        return false;
+    }
+}
+template <class LDS>
+__device__ __forceinline__ void stack_push(LDS& S, const MParams& M, const uint32_t id, const uint32_t g, int& sp, const int ref, const float t)
+{
+    const int2 en = make_int2(ref, __float_as_int(t));
+    if (sp < POOL_LV) S.stk[sp][id] = en;
+    if (__ballot(sp >= POOL_LV)) {
+        if (sp >= POOL_LV) M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+    }
+    sp++;
+}
+
+// One step at a node of the 4-wide tree (rays with finite operands, CRT_TRAVERSAL_FAST): four child boxes as two packed pairs,
+// the nearest hit child next, the others pushed farthest first with their entry distances.  Which children are visited, and in
+// which order, does not change the result (crt_trace.h); the boxes and the test are the reference's (hit_AABB with minima /
+// maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
+template <bool STATS, class LDS>
+__device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp)
+{
+    const float4* nd = sc.nodes4 + (size_t)ref * 8;
+    const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
+    if (STATS) tc.inner++;
+    bool h0, h1, h2, h3;
+    float t0, t1, t2, t3;
+    slab_pair(a0, a1, a2, o, inv, o, false, h0, h1, t0, t1);
+    slab_pair(b0, b1, b2, o, inv, o, false, h2, h3, t2, t3);
+    const float inf = pinf();
+    // a child that is missed or starts beyond the pruning bound sorts last
+    t0 = (h0 && !(t0 > bound)) ? t0 : inf; t1 = (h1 && !(t1 > bound)) ? t1 : inf;
+    t2 = (h2 && !(t2 > bound)) ? t2 : inf; t3 = (h3 && !(t3 > bound)) ? t3 : inf;
+    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    const int n = (t0 < inf ? 1 : 0) + (t1 < inf ? 1 : 0) + (t2 < inf ? 1 : 0) + (t3 < inf ? 1 : 0);
+    // ascending by entry distance: (0,1)(2,3)(0,2)(1,3)(1,2)
+#define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
+    CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2) CRT_CE(t1, r1, t3, r3) CRT_CE(t1, r1, t2, r2)
+#undef CRT_CE
+    if (n > 3) stack_push(S, M, id, g, sp, r3, t3);
+    if (n > 2) stack_push(S, M, id, g, sp, r2, t2);
+    if (n > 1) stack_push(S, M, id, g, sp, r1, t1);
+    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    if (n > 0) { ref = r0; return false; }
+    return stack_pop<0>(S, M, id, g, bound, sp, ref);
+}
+
+// One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
+// visit order, no pruning) or, for the handful of FAST rays with non-finite operands, reference arithmetic on that topology
+// with ordering and pruning.  d = direction (the sign selects the near plane, DeviceBVH.cuh:101-119).
+template <int MODE, bool STATS, class LDS>
+__device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+                                            const F3 d, const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp)
+{
+    const float4* nd = sc.nodes3 + (size_t)ref * 4;
+    const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
+    const float2 n3 = *(const float2*)(nd + 3);
+    if (STATS) tc.inner++;
+    bool hl, hr;
+    float tl, tr;
+    slab_pair(n0, n1, n2, o, inv, d, true, hl, hr, tl, tr);
+    const int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
+    bool left_first;
+    if (MODE == 1) {
+        left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
+    } else {
+        hl = hl && !(tl > bound);
+        hr = hr && !(tr > bound);
+        left_first = tl <= tr;
+    }
+    const bool both = hl && hr, any = hl || hr;
+    const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+    if (both) {
+        stack_push(S, M, id, g, sp, left_first ? rref : lref, left_first ? tr : tl);
+        if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    }
+    if (any) { ref = near_ref; return false; }
+    return stack_pop<MODE>(S, M, id, g, bound, sp, ref);
+}
+
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
 template <int MODE, bool STATS, bool ALL = false>
@@ -1350,72 +1447,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const uint32_t qd = S.D[id];
                 CRT_SEC3(1, qa.x + qc.x + __uint_as_float(qd))
                 int ref = __float_as_int(qc.w);
-                const float4* nd = sc.nodes3 + (size_t)ref * 4;
-                const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2];
-                const float2 n3 = *(const float2*)(nd + 3);
-                CRT_SEC3(2, n0.x + n1.x + n2.x + n3.x)
                 const F3 o = f3(qa.x, qa.y, qa.z), inv = f3(qc.x, qc.y, qc.z);
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
                 const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w) : FLT_MAX;
-                if (STATS) tc.inner++;
-                bool hl, hr;
-                float tl, tr;
+                bool done = false;
                 if (MODE == 1) {
                     const float4 qb = S.B[id];
-                    slab_pair(n0, n1, n2, o, inv, f3(qb.x, qb.y, qb.z), true, hl, hr, tl, tr);
+                    done = inner2_step<1, STATS>(sc, S, M, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                 } else {
-                    slab_pair(n0, n1, n2, o, inv, o, false, hl, hr, tl, tr);
-                    if (__ballot((qd & RF_EXACT) != 0)) { // a handful of rays per frame
-                        if (qd & RF_EXACT) {
+                    const bool ex = (qd & RF_EXACT) != 0;
+                    if (!ex) done = inner4_step<STATS>(sc, S, M, id, g, o, inv, bound, ref, sp, tc, max_sp);
+                    if (__ballot(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
+                        if (ex) {
                             const float4 qb = S.B[id];
-                            slab_pair(n0, n1, n2, o, inv, f3(qb.x, qb.y, qb.z), true, hl, hr, tl, tr);
+                            done = inner2_step<0, STATS>(sc, S, M, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                         }
                     }
-                }
-#ifdef CRT_STAMPS
-                {
-                    float dbg_acc = 0.0f;
-                    for (int x = 0; x < M3.dbg_loads; x++) dbg_acc += sc.nodes3[(size_t)(ref ^ (x + 1)) * 4 + (x & 3)].x; // sensitivity probe: more divergent 16 B loads
-                    for (int x = 0; x < M3.dbg_valu; x++) dbg_acc = dbg_acc * 1.0001f + inv.x;                            // sensitivity probe: more VALU
-                    if (dbg_acc == 1.2345e-30f) tl = 0.0f;
-                }
-#endif
-                const int lref = __float_as_int(n3.x), rref = __float_as_int(n3.y);
-                bool left_first;
-                if (MODE == 1) {
-                    left_first = false; // push lc, visit rc first (DeviceBVH.cuh:154-166)
-                } else {
-                    hl = hl && !(tl > bound);
-                    hr = hr && !(tr > bound);
-                    left_first = tl <= tr;
-                }
-                const bool both = hl && hr, any = hl || hr;
-                const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
-                if (both) {
-                    const int2 en = make_int2(left_first ? rref : lref, __float_as_int(left_first ? tr : tl));
-                    if (sp < POOL_LV) S.stk[sp][id] = en;
-                    if (__ballot(sp >= POOL_LV)) {
-                        if (sp >= POOL_LV) M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
-                    }
-                    sp++;
-                    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-                }
-                ref = any ? near_ref : ref;
-                CRT_SEC3(3, ref + sp)
-                bool done = false, need_pop = !any;
-                while (need_pop) { // pop until a node that is still within the pruning bound
-                    if (sp == 0) { done = true; break; }
-                    sp--;
-                    // the LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane
-                    // choice between the two address spaces would compile to a flat load that waits on both memory pipes
-                    int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
-                    if (__ballot(sp >= POOL_LV)) {
-                        if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
-                    }
-                    ref = en.x;
-                    if (MODE == 0 && __int_as_float(en.y) > bound) continue;
-                    need_pop = false;
                 }
                 CRT_SEC3(4, ref + sp)
                 S.C[id].w = __int_as_float(ref);
@@ -1726,7 +1774,8 @@ const int kMaxBatch = 64;
 
 struct crt_scene {
     int device = 0;
-    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm;
+    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4;
+    int depth4 = 1; // depth of the 4-wide tree
     uint32_t max_leaf = 0; // triangles in the largest leaf
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint4> lights;
@@ -2370,6 +2419,75 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             nodes3[q * 4 + 2] = make_float4(b.y, e.y, b.z, e.z);
             nodes3[q * 4 + 3] = make_float4(as_float(ref3(lr)), as_float(ref3(rr)), 0.0f, 0.0f);
         }
+        // ---- 4-wide tree for the rays with finite operands: the SAH tree collapsed (crt_device.h, nodes4) ----
+        std::vector<float4> nodes4;
+        int32_t root4 = ref3(root_fast);
+        int depth4 = 1;
+        if (root4 >= 0) {
+            struct Child { float lo[3], hi[3]; int32_t ref; }; // ref: nodes3 index (>= 0) or leaf ref (< 0)
+            auto children_of = [&](int32_t q, Child out[2]) {
+                const float4 n0 = nodes3[q * 4ull], n1 = nodes3[q * 4ull + 1], n2 = nodes3[q * 4ull + 2], n3 = nodes3[q * 4ull + 3];
+                out[0] = Child{{n0.x, n0.z, n1.x}, {n1.z, n2.x, n2.z}, 0};
+                out[1] = Child{{n0.y, n0.w, n1.y}, {n1.w, n2.y, n2.w}, 0};
+                std::memcpy(&out[0].ref, &n3.x, 4); std::memcpy(&out[1].ref, &n3.y, 4);
+            };
+            auto area = [](const Child& c) {
+                const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+                return dx * dy + dy * dz + dz * dx;
+            };
+            struct Todo { int32_t node2; int32_t slot; int depth; }; // slot: index of the BVH4 node to fill
+            std::vector<Todo> todo;
+            nodes4.resize(8);
+            todo.push_back(Todo{root4, 0, 1});
+            root4 = 0;
+            const float qn_ = std::numeric_limits<float>::quiet_NaN();
+            for (size_t t = 0; t < todo.size(); t++) {
+                const Todo cur = todo[t];
+                depth4 = std::max(depth4, cur.depth + 1);
+                std::vector<Child> ch(2);
+                children_of(cur.node2, ch.data());
+                while (ch.size() < 4) { // open the largest inner child
+                    int best = -1;
+                    double ba = -1.0;
+                    for (size_t i = 0; i < ch.size(); i++)
+                        if (ch[i].ref >= 0 && area(ch[i]) > ba) { ba = area(ch[i]); best = (int)i; }
+                    if (best < 0) break;
+                    Child two[2];
+                    children_of(ch[best].ref, two);
+                    ch[best] = two[0];
+                    ch.push_back(two[1]);
+                }
+                int32_t refs[4];
+                float lo[4][3], hi[4][3];
+                for (int i = 0; i < 4; i++) {
+                    if (i < (int)ch.size()) {
+                        for (int a = 0; a < 3; a++) { lo[i][a] = ch[i].lo[a]; hi[i][a] = ch[i].hi[a]; }
+                        if (ch[i].ref >= 0) {
+                            refs[i] = (int32_t)(nodes4.size() / 8);
+                            nodes4.resize(nodes4.size() + 8);
+                            todo.push_back(Todo{ch[i].ref, refs[i], cur.depth + 1});
+                        } else refs[i] = ch[i].ref;
+                    } else { // empty slot: a box of NaNs fails every comparison of the slab test
+                        for (int a = 0; a < 3; a++) { lo[i][a] = qn_; hi[i][a] = qn_; }
+                        refs[i] = ~0x7ffffff0; // (never followed)
+                    }
+                }
+                float4* o = &nodes4[(size_t)cur.slot * 8];
+                for (int pr = 0; pr < 2; pr++) { // children (0,1) then (2,3), pair-packed like nodes3
+                    const int i = 2 * pr, j = i + 1;
+                    o[pr * 3 + 0] = make_float4(lo[i][0], lo[j][0], lo[i][1], lo[j][1]);
+                    o[pr * 3 + 1] = make_float4(lo[i][2], lo[j][2], hi[i][0], hi[j][0]);
+                    o[pr * 3 + 2] = make_float4(hi[i][1], hi[j][1], hi[i][2], hi[j][2]);
+                }
+                o[6] = make_float4(as_float(refs[0]), as_float(refs[1]), as_float(refs[2]), as_float(refs[3]));
+                o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        if (nodes4.empty()) nodes4.resize(8);
+        sc->nodes4.upload(nodes4);
+        sc->dev.nodes4 = sc->nodes4.p;
+        sc->dev.root4 = root4;
+        sc->depth4 = depth4;
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
@@ -2403,7 +2521,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->n_tris = d->n_tris;
         sc->n_mats = d->n_materials;
         // Both traversal modes hold at most one pending sibling per tree level.
-        sc->stack_cap = depth + 2;
+        sc->stack_cap = std::max(depth + 2, 3 * sc->depth4 + 2); // BVH2: one pending sibling per level; BVH4: up to three
         *out = sc;
         return CRT_OK;
     } catch (const HipFail& f) {
