@@ -1263,6 +1263,7 @@ __device__ __forceinline__ bool stack_pop(LDS& S, const MParams& M, const uint32
         if (sp == 0) return true;
         sp--;
         int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
+        asm volatile("" : "+v"(en.x), "+v"(en.y)); // (pins the LDS read: see above)
         if (__ballot(sp >= POOL_LV)) {
             if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
         }
