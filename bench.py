@@ -139,8 +139,8 @@ def main():
 
     if rank == 0:
         # ---- roofline: bytes per ray from the counting kernels on a spp=8 slice of the same frame ----
-        def visit_bytes(st):
-            return (64.0 * st["inner_pops"] + 8.0 * st["leaf_pops"] + 36.0 * st["tri_tests"] + 16.0 * st["hits"]) / st["rays"]
+        def visit_bytes(st, node_bytes=64.0):
+            return (node_bytes * st["inner_pops"] + 8.0 * st["leaf_pops"] + 36.0 * st["tri_tests"] + 16.0 * st["hits"]) / st["rays"]
 
         render.set_spp(8)
         render.traversal = crt.TRAVERSAL_REFERENCE
@@ -149,7 +149,7 @@ def main():
         ref_visits = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
         render.traversal = crt.TRAVERSAL_FAST
         render.run_view(eye, inv_view, fov, stats=True, want_mean=False, width=args.width, height=args.height)
-        b_ray_visited = visit_bytes(render.stats)
+        b_ray_visited = visit_bytes(render.stats, 112.0)  # the FAST traversal walks the 4-wide tree: 4 boxes + 4 refs per node
         launches = max(1, int(np.mean(kernel_launches)))
         k_ms_total = float(np.mean(kernel_ms))           # sum of the kernel's launch durations of one frame (rank 0)
         k_ms = k_ms_total / launches                     # average launch duration
