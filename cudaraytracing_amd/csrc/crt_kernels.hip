@@ -1289,7 +1289,7 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams& M, const uint3
 // maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
-                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp)
+                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu)
 {
     const float4* nd = sc.nodes4 + (size_t)ref * 8;
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
@@ -1298,6 +1298,16 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     float t0, t1, t2, t3;
     slab_pair(a0, a1, a2, o, inv, o, false, h0, h1, t0, t1);
     slab_pair(b0, b1, b2, o, inv, o, false, h2, h3, t2, t3);
+#ifdef CRT_STAMPS
+    { // sensitivity probes (tools/diag_sens.sh): result-neutral extra divergent 16 B loads / dependent VALU per inner step
+        float dbg_acc = 0.0f;
+        for (int x = 0; x < dbg_loads; x++) dbg_acc += sc.nodes4[(size_t)(ref ^ (x + 1)) * 8 + (x & 7)].x;
+        for (int x = 0; x < dbg_valu; x++) dbg_acc = dbg_acc * 1.0001f + inv.x;
+        if (dbg_acc == 1.2345e-30f) t0 = 0.0f;
+    }
+#else
+    (void)dbg_loads; (void)dbg_valu;
+#endif
     const float inf = pinf();
     // a child that is missed or starts beyond the pruning bound sorts last
     t0 = (h0 && !(t0 > bound)) ? t0 : inf; t1 = (h1 && !(t1 > bound)) ? t1 : inf;
@@ -1458,7 +1468,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     done = inner2_step<1, STATS>(sc, S, M, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
-                    if (!ex) done = inner4_step<STATS>(sc, S, M, id, g, o, inv, bound, ref, sp, tc, max_sp);
+                    if (!ex) done = inner4_step<STATS>(sc, S, M, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
                     if (__ballot(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
                         if (ex) {
                             const float4 qb = S.B[id];
