@@ -1224,8 +1224,8 @@ __device__ __forceinline__ void slab_pair(const float4 n0, const float4 n1, cons
         xl = minf_ref(minf_ref(nx ? tx0.x : tx1.x, ny ? ty0.x : ty1.x), nz ? tz0.x : tz1.x);
         xr = minf_ref(minf_ref(nx ? tx0.y : tx1.y, ny ? ty0.y : ty1.y), nz ? tz0.y : tz1.y);
     }
-    hl = el <= xl + CRT_EPSILON && xl >= 0;
-    hr = er <= xr + CRT_EPSILON && xr >= 0;
+    hl = (el <= xl + CRT_EPSILON) & (xl >= 0);
+    hr = (er <= xr + CRT_EPSILON) & (xr >= 0);
     tl = el; tr = er;
 }
 
@@ -1248,8 +1248,8 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     const v2f gamma = (s2x * v2s(d.x) + (s2y * v2s(d.y) + s2z * v2s(d.z))) * rcp;
     const v2f t = (s2x * e2x + (s2y * e2y + s2z * e2z)) * rcp;
     const v2f alpha = v2s(1.0f) - beta - gamma;
-    a0 = 0 < alpha.x && alpha.x < 1 && 0 < beta.x && beta.x < 1 && 0 < gamma.x && gamma.x < 1 && t.x > CRT_EPSILON;
-    a1 = 0 < alpha.y && alpha.y < 1 && 0 < beta.y && beta.y < 1 && 0 < gamma.y && gamma.y < 1 && t.y > CRT_EPSILON;
+    a0 = (0 < alpha.x) & (alpha.x < 1) & (0 < beta.x) & (beta.x < 1) & (0 < gamma.x) & (gamma.x < 1) & (t.x > CRT_EPSILON);
+    a1 = (0 < alpha.y) & (alpha.y < 1) & (0 < beta.y) & (beta.y < 1) & (0 < gamma.y) & (gamma.y < 1) & (t.y > CRT_EPSILON);
     t0 = t.x; t1 = t.y;
 }
 
@@ -1310,8 +1310,8 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
 #endif
     const float inf = pinf();
     // a child that is missed or starts beyond the pruning bound sorts last
-    t0 = (h0 && !(t0 > bound)) ? t0 : inf; t1 = (h1 && !(t1 > bound)) ? t1 : inf;
-    t2 = (h2 && !(t2 > bound)) ? t2 : inf; t3 = (h3 && !(t3 > bound)) ? t3 : inf;
+    t0 = (h0 & !(t0 > bound)) ? t0 : inf; t1 = (h1 & !(t1 > bound)) ? t1 : inf;
+    t2 = (h2 & !(t2 > bound)) ? t2 : inf; t3 = (h3 & !(t3 > bound)) ? t3 : inf;
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
     const int n = (t0 < inf ? 1 : 0) + (t1 < inf ? 1 : 0) + (t2 < inf ? 1 : 0) + (t3 < inf ? 1 : 0);
     // ascending by entry distance: (0,1)(2,3)(0,2)(1,3)(1,2)
@@ -1515,16 +1515,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     a1 = a1 && two;
                     if (STATS) { tc.tests += two ? 2u : 1u; }
                     if (any_hit) {
-                        const bool b0 = a0 && (T - t0 > CRT_EPSILON);
-                        const bool b1 = a1 && (T - t1 > CRT_EPSILON);
-                        done = b0 || b1;
+                        const bool b0 = a0 & (T - t0 > CRT_EPSILON);
+                        const bool b1 = a1 & (T - t1 > CRT_EPSILON);
+                        done = b0 | b1;
                         tri = b0 ? it : (b1 ? it + 1 : tri);
                     } else {
                         // ascending index, strict <: the first of equal t inside a leaf wins (DeviceBVH.cuh:34-41); across leaves the
                         // larger leaf start wins (reference visit order, see crt_trace.h)
-                        const bool w0 = a0 && (t0 < T || (t0 == T && it0 > best_leaf));
+                        const bool w0 = a0 & ((t0 < T) | ((t0 == T) & (it0 > best_leaf)));
                         T = w0 ? t0 : T; tri = w0 ? it : tri; best_leaf = w0 ? it0 : best_leaf;
-                        const bool w1 = a1 && (t1 < T || (t1 == T && it0 > best_leaf));
+                        const bool w1 = a1 & ((t1 < T) | ((t1 == T) & (it0 > best_leaf)));
                         T = w1 ? t1 : T; tri = w1 ? it + 1 : tri; best_leaf = w1 ? it0 : best_leaf;
                     }
                     left -= 2;
