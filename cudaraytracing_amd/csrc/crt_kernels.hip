@@ -902,11 +902,11 @@ struct MParams {
 #define RF_EXACT 0x10000000u   /* reference box arithmetic (non-finite operands) */
 #define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
 #ifndef POOL3_P
-#define POOL3_P 126         /* 126 x 76 B + rings = 10 216 B: 16 waves per CU */
+#define POOL3_P 148         /* 148 x 64 B + rings = 10 212 B: 16 waves per CU */
 #endif
-#define POOL3_QCAP 128      /* ring capacity: power of two >= POOL3_P, ids fit a byte */
-#if POOL3_P > POOL3_QCAP || POOL3_QCAP > 256
-#error "POOL3_QCAP must be a power of two in [POOL3_P, 256]"
+#define POOL3_QCAP ((POOL3_P + 3) & ~3) /* ring capacity (any number >= POOL3_P: indices wrap by compare, not by mask); ids fit a byte */
+#if POOL3_P > 256
+#error "ray ids of a pool must fit a byte"
 #endif
 #define CRT_MEGA3_MAX_LEAF 65535 /* best-triangle offset inside its leaf is kept in 16 bits */
 
@@ -916,13 +916,14 @@ struct Pool3Lds {
     float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
     float4 B[POOL3_P];           // direction.xyz, bits(best triangle, -1 = none)
     float4 C[POOL3_P];           // 1/direction.xyz (Ray.cuh:14), bits(current node ref)
-    int2 stk[POOL_LV][POOL3_P];  // traversal stack (node ref, t_enter); deeper levels spill to global memory
+    int stk[POOL_LV][POOL3_P];   // traversal stack (node refs); deeper levels spill to global memory
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N][POOL3_QCAP];
 };
 
 struct MParams3 {
     MParams M;
+    int* spill;                  // [level - POOL_LV][pool slot] stack entries beyond the LDS levels
     uint32_t force_exact;        // CRT_FLAG_FORCE_EXACT
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
@@ -937,6 +938,9 @@ __device__ __forceinline__ float fmin3(float a, float b, float c) { return __bui
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 __device__ __forceinline__ v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ v2f v2s(float a) { v2f r; r.x = a; r.y = a; return r; }
+
+// Ring index in [0, 2 * POOL3_QCAP) -> [0, POOL3_QCAP).
+__device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)POOL3_QCAP); }
 
 // Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
 // or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
@@ -1253,32 +1257,30 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     t0 = t.x; t1 = t.y;
 }
 
-// Pops the traversal stack of ray `id` until a node that is still within the pruning bound; returns true when the stack ran
-// empty (the ray is finished).  The LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform
-// branch: a per-lane choice between the two address spaces would compile to a flat load that waits on both memory pipes.
-template <int MODE, class LDS>
-__device__ __forceinline__ bool stack_pop(LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const float bound, int& sp, int& ref)
+// Pops the traversal stack of ray `id`; returns true when it is empty (the ray is finished).  An entry is the node ref alone:
+// a node that has fallen behind the pruning bound since it was pushed is weeded out by its own step (keeping the entry
+// distance to drop such entries here measured no gain on either scene and costs 4 B of LDS per level).  The LDS levels are
+// read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane choice between the two address
+// spaces would compile to a flat load that waits on both memory pipes.
+template <class LDS>
+__device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref)
 {
-    for (;;) {
-        if (sp == 0) return true;
-        sp--;
-        int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
-        asm volatile("" : "+v"(en.x), "+v"(en.y)); // (pins the LDS read: see above)
-        if (__ballot(sp >= POOL_LV)) {
-            if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
-        }
-        ref = en.x;
-        if (MODE == 0 && __int_as_float(en.y) > bound) continue;
-        return false;
+    if (sp == 0) return true;
+    sp--;
+    int en = S.stk[sp < POOL_LV ? sp : 0][id];
+    asm volatile("" : "+v"(en)); // (pins the LDS read: see above)
+    if (__ballot(sp >= POOL_LV)) {
+        if (sp >= POOL_LV) en = M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g];
     }
+    ref = en;
+    return false;
 }
 template <class LDS>
-__device__ __forceinline__ void stack_push(LDS& S, const MParams& M, const uint32_t id, const uint32_t g, int& sp, const int ref, const float t)
+__device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref)
 {
-    const int2 en = make_int2(ref, __float_as_int(t));
-    if (sp < POOL_LV) S.stk[sp][id] = en;
+    if (sp < POOL_LV) S.stk[sp][id] = ref;
     if (__ballot(sp >= POOL_LV)) {
-        if (sp >= POOL_LV) M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g] = en;
+        if (sp >= POOL_LV) M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g] = ref;
     }
     sp++;
 }
@@ -1288,7 +1290,7 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams& M, const uint3
 // which order, does not change the result (crt_trace.h); the boxes and the test are the reference's (hit_AABB with minima /
 // maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, class LDS>
-__device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+__device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
                                             const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu)
 {
     const float4* nd = sc.nodes4 + (size_t)ref * 8;
@@ -1318,19 +1320,19 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
 #define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
     CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2) CRT_CE(t1, r1, t3, r3) CRT_CE(t1, r1, t2, r2)
 #undef CRT_CE
-    if (n > 3) stack_push(S, M, id, g, sp, r3, t3);
-    if (n > 2) stack_push(S, M, id, g, sp, r2, t2);
-    if (n > 1) stack_push(S, M, id, g, sp, r1, t1);
+    if (n > 3) stack_push(S, M, id, g, sp, r3);
+    if (n > 2) stack_push(S, M, id, g, sp, r2);
+    if (n > 1) stack_push(S, M, id, g, sp, r1);
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
     if (n > 0) { ref = r0; return false; }
-    return stack_pop<0>(S, M, id, g, bound, sp, ref);
+    return stack_pop(S, M, id, g, sp, ref);
 }
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
 // visit order, no pruning) or, for the handful of FAST rays with non-finite operands, reference arithmetic on that topology
 // with ordering and pruning.  d = direction (the sign selects the near plane, DeviceBVH.cuh:101-119).
 template <int MODE, bool STATS, class LDS>
-__device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MParams& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+__device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
                                             const F3 d, const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp)
 {
     const float4* nd = sc.nodes3 + (size_t)ref * 4;
@@ -1352,11 +1354,11 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
     const bool both = hl && hr, any = hl || hr;
     const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
     if (both) {
-        stack_push(S, M, id, g, sp, left_first ? rref : lref, left_first ? tr : tl);
+        stack_push(S, M, id, g, sp, left_first ? rref : lref);
         if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
     }
     if (any) { ref = near_ref; return false; }
-    return stack_pop<MODE>(S, M, id, g, bound, sp, ref);
+    return stack_pop(S, M, id, g, sp, ref);
 }
 
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
@@ -1393,9 +1395,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
 
     // ring state: wave-uniform scalars
-    int qn[PH3_N], qh[PH3_N];
+    int qn[PH3_N], qh[PH3_N], qt[PH3_N]; // entries, head, tail (head and tail in [0, POOL3_QCAP))
 #pragma unroll
-    for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; }
+    for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; qt[p] = 0; }
     // every ray of the pool starts in LC with a path in stage NEW
     {
         const int n_valid = (int)min((uint32_t)POOL3_P, pl.n > base ? pl.n - base : 0u);
@@ -1404,6 +1406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             pl.la[base + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_NEW << 8));
         }
         qn[PH3_LC] = n_valid;
+        qt[PH3_LC] = n_valid >= POOL3_QCAP ? n_valid - POOL3_QCAP : n_valid;
     }
 
 // appends the processed rays (lane active = `on`, ray `id`) to the ring of their new phase
@@ -1413,16 +1416,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const unsigned long long m = __ballot(mine);                                                                       \
         if (m) {                                                                                                           \
             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
-            if (mine) S.ring[p][(qh[p] + qn[p] + rank) & (POOL3_QCAP - 1)] = (uint8_t)id;                                  \
-            qn[p] += (int)__popcll(m);                                                                                     \
+            if (mine) S.ring[p][ring_wrap((uint32_t)(qt[p] + rank))] = (uint8_t)id;                                          \
+            const int add = (int)__popcll(m);                                                                              \
+            qn[p] += add;                                                                                                  \
+            qt[p] += add;                                                                                                  \
+            if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
         }                                                                                                                  \
     }
 // takes the (up to) 64 oldest rays of ring p
 #define POP3(p)                                                                                                            \
     const int take = min(64, qn[p]);                                                                                       \
     const bool on = lane < take;                                                                                           \
-    const uint32_t id = S.ring[p][(qh[p] + lane) & (POOL3_QCAP - 1)];                                                      \
-    qh[p] = (qh[p] + take) & (POOL3_QCAP - 1);                                                                             \
+    const uint32_t id = S.ring[p][ring_wrap((uint32_t)(qh[p] + lane))];                                                    \
+    qh[p] += take;                                                                                                         \
+    if (qh[p] >= POOL3_QCAP) qh[p] -= POOL3_QCAP;                                                                          \
     qn[p] -= take;                                                                                                         \
     const uint32_t g = base + id;                                                                                          \
     uint32_t nph = PH3_NONE;
@@ -1465,14 +1472,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 bool done = false;
                 if (MODE == 1) {
                     const float4 qb = S.B[id];
-                    done = inner2_step<1, STATS>(sc, S, M, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
+                    done = inner2_step<1, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
-                    if (!ex) done = inner4_step<STATS>(sc, S, M, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
+                    if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
                     if (__ballot(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
                         if (ex) {
                             const float4 qb = S.B[id];
-                            done = inner2_step<0, STATS>(sc, S, M, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
+                            done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                         }
                     }
                 }
@@ -1531,21 +1538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 if (STATS) tc.leaf++;
                 if (!any_hit && tri >= 0) qd |= RF_HASHIT;
-                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(T) : FLT_MAX;
-                bool need_pop = !done;
-                while (need_pop) { // pop until a node that is still within the pruning bound
-                    if (sp == 0) { done = true; break; }
-                    sp--;
-                    // the LDS levels are read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane
-                    // choice between the two address spaces would compile to a flat load that waits on both memory pipes
-                    int2 en = S.stk[sp < POOL_LV ? sp : 0][id];
-                    if (__ballot(sp >= POOL_LV)) {
-                        if (sp >= POOL_LV) en = M.spill[(size_t)(sp - POOL_LV) * M.spill_stride + g];
-                    }
-                    ref = en.x;
-                    if (MODE == 0 && __int_as_float(en.y) > bound) continue;
-                    need_pop = false;
-                }
+                if (!done) done = stack_pop(S, M3, id, g, sp, ref);
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
@@ -2132,6 +2125,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 {
                     MParams3 M3;
                     M3.M = M;
+                    M3.spill = (int*)sc->spill[0].p; // (one word per entry; the buffer is sized for the two-word entries of k_trace)
                     M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
