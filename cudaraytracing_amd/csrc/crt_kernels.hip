@@ -1233,6 +1233,23 @@ __device__ __forceinline__ void slab_pair(const float4 n0, const float4 n1, cons
     tl = el; tr = er;
 }
 
+// slab_pair for rays with finite operands, with the pruning test folded in: returns each child's entry distance, or +inf when
+// the box is missed (hit_AABB: t_enter <= t_exit + EPSILON && t_exit >= 0) or entered beyond `bound`
+// (t_enter <= min(t_exit + EPSILON, bound) is the conjunction of the two upper limits; a NaN box -- an empty slot -- fails).
+__device__ __forceinline__ void slab_pair_pruned(const float4 n0, const float4 n1, const float4 n2, const F3 o, const F3 inv, const float bound,
+                                                 float& tl, float& tr)
+{
+    const v2f tx0 = (v2(n0.x, n0.y) - v2s(o.x)) * v2s(inv.x), ty0 = (v2(n0.z, n0.w) - v2s(o.y)) * v2s(inv.y), tz0 = (v2(n1.x, n1.y) - v2s(o.z)) * v2s(inv.z);
+    const v2f tx1 = (v2(n1.z, n1.w) - v2s(o.x)) * v2s(inv.x), ty1 = (v2(n2.x, n2.y) - v2s(o.y)) * v2s(inv.y), tz1 = (v2(n2.z, n2.w) - v2s(o.z)) * v2s(inv.z);
+    const float el = fmax3(__builtin_fminf(tx0.x, tx1.x), __builtin_fminf(ty0.x, ty1.x), __builtin_fminf(tz0.x, tz1.x));
+    const float er = fmax3(__builtin_fminf(tx0.y, tx1.y), __builtin_fminf(ty0.y, ty1.y), __builtin_fminf(tz0.y, tz1.y));
+    const float xl = fmin3(__builtin_fmaxf(tx0.x, tx1.x), __builtin_fmaxf(ty0.x, ty1.x), __builtin_fmaxf(tz0.x, tz1.x));
+    const float xr = fmin3(__builtin_fmaxf(tx0.y, tx1.y), __builtin_fmaxf(ty0.y, ty1.y), __builtin_fmaxf(tz0.y, tz1.y));
+    const float inf = pinf();
+    tl = ((el <= __builtin_fminf(xl + CRT_EPSILON, bound)) & (xl >= 0)) ? el : inf;
+    tr = ((er <= __builtin_fminf(xr + CRT_EPSILON, bound)) & (xr >= 0)) ? er : inf;
+}
+
 // The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
 // the t > EPSILON filter of DeviceBVHNode::hit (DeviceBVH.cuh:37); lane .x = first triangle, .y = second.
 __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4 g4, const F3 o, const F3 d,
@@ -1269,7 +1286,7 @@ __device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint
     sp--;
     int en = S.stk[sp < POOL_LV ? sp : 0][id];
     asm volatile("" : "+v"(en)); // (pins the LDS read: see above)
-    if (__ballot(sp >= POOL_LV)) {
+    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
         if (sp >= POOL_LV) en = M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g];
     }
     ref = en;
@@ -1279,7 +1296,7 @@ template <class LDS>
 __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref)
 {
     if (sp < POOL_LV) S.stk[sp][id] = ref;
-    if (__ballot(sp >= POOL_LV)) {
+    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
         if (sp >= POOL_LV) M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g] = ref;
     }
     sp++;
@@ -1296,10 +1313,9 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     const float4* nd = sc.nodes4 + (size_t)ref * 8;
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
     if (STATS) tc.inner++;
-    bool h0, h1, h2, h3;
-    float t0, t1, t2, t3;
-    slab_pair(a0, a1, a2, o, inv, o, false, h0, h1, t0, t1);
-    slab_pair(b0, b1, b2, o, inv, o, false, h2, h3, t2, t3);
+    float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
+    slab_pair_pruned(a0, a1, a2, o, inv, bound, t0, t1);
+    slab_pair_pruned(b0, b1, b2, o, inv, bound, t2, t3);
 #ifdef CRT_STAMPS
     { // sensitivity probes (tools/diag_sens.sh): result-neutral extra divergent 16 B loads / dependent VALU per inner step
         float dbg_acc = 0.0f;
@@ -1311,20 +1327,25 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     (void)dbg_loads; (void)dbg_valu;
 #endif
     const float inf = pinf();
-    // a child that is missed or starts beyond the pruning bound sorts last
-    t0 = (h0 & !(t0 > bound)) ? t0 : inf; t1 = (h1 & !(t1 > bound)) ? t1 : inf;
-    t2 = (h2 & !(t2 > bound)) ? t2 : inf; t3 = (h3 & !(t3 > bound)) ? t3 : inf;
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
-    const int n = (t0 < inf ? 1 : 0) + (t1 < inf ? 1 : 0) + (t2 < inf ? 1 : 0) + (t3 < inf ? 1 : 0);
     // ascending by entry distance: (0,1)(2,3)(0,2)(1,3)(1,2)
 #define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
     CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2) CRT_CE(t1, r1, t3, r3) CRT_CE(t1, r1, t2, r2)
 #undef CRT_CE
-    if (n > 3) stack_push(S, M, id, g, sp, r3);
-    if (n > 2) stack_push(S, M, id, g, sp, r2);
-    if (n > 1) stack_push(S, M, id, g, sp, r1);
+    // the children to visit are a prefix of the sorted four; all but the nearest go on the stack, farthest first
+    const bool c0 = t0 < inf, c1 = t1 < inf, c2 = t2 < inf, c3 = t3 < inf;
+    const int l3 = sp, l2 = l3 + (c3 ? 1 : 0), l1 = l2 + (c2 ? 1 : 0);
+    if (c3 & (l3 < POOL_LV)) S.stk[l3][id] = r3;
+    if (c2 & (l2 < POOL_LV)) S.stk[l2][id] = r2;
+    if (c1 & (l1 < POOL_LV)) S.stk[l1][id] = r1;
+    if (__builtin_amdgcn_ballot_w64(c1 & (l1 >= POOL_LV))) { // one check per step for the levels beyond LDS (l1 is the highest)
+        if (c3 & (l3 >= POOL_LV)) M.spill[(size_t)(l3 - POOL_LV) * M.M.spill_stride + g] = r3;
+        if (c2 & (l2 >= POOL_LV)) M.spill[(size_t)(l2 - POOL_LV) * M.M.spill_stride + g] = r2;
+        if (c1 & (l1 >= POOL_LV)) M.spill[(size_t)(l1 - POOL_LV) * M.M.spill_stride + g] = r1;
+    }
+    sp = l1 + (c1 ? 1 : 0);
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-    if (n > 0) { ref = r0; return false; }
+    if (c0) { ref = r0; return false; }
     return stack_pop(S, M, id, g, sp, ref);
 }
 
@@ -1369,7 +1390,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __shared__ Pool3Lds S;
     const MParams& M = M3.M;
     const LParams& P = M.P;
-    const DevScene& sc = M.sc;
+    const DevScene& sc = P.sc; // (one copy of the scene pointers in scalar registers: the logic phases use P.sc too)
     const Pool& pl = P.pool;
     const int lane = threadIdx.x;
     const uint32_t base = blockIdx.x * (uint32_t)POOL3_P; // first global slot of this wave's pool
@@ -1434,6 +1455,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const uint32_t g = base + id;                                                                                          \
     uint32_t nph = PH3_NONE;
 
+// The logic phases read their parameters from the kernel-argument segment again, through a pointer the compiler cannot see
+// through: parameters that are only needed there (camera, tiling, work-item cursors, pool planes ...) would otherwise be
+// hoisted into scalar registers for the whole kernel and push the ring cursors of the traversal steps out into VGPR lanes.
+#ifndef CRT_NO_LOCAL_PARAMS
+#define LOGIC_PARAMS()                                                                                                     \
+    const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(ka_));                                                                                          \
+    union { LParams p; uint32_t w[sizeof(LParams) / 4]; } pu_;                                                             \
+    {                                                                                                                      \
+        const __attribute__((address_space(4))) uint32_t* src_ =                                                           \
+            (const __attribute__((address_space(4))) uint32_t*)(ka_ + offsetof(MParams3, M) + offsetof(MParams, P));       \
+        _Pragma("unroll") for (unsigned i_ = 0; i_ < sizeof(LParams) / 4; i_++) pu_.w[i_] = src_[i_];                      \
+    }                                                                                                                      \
+    const LParams& Pl = pu_.p;                                                                                             \
+    Tables<false> tl;                                                                                                      \
+    tl.mats = Pl.sc.mats; tl.lights = Pl.sc.lights;
+#else
+#define LOGIC_PARAMS() const LParams& Pl = P; const Tables<false>& tl = tb;
+#endif
+
     for (;;) {
         // ---- choose a phase: the ring with the fullest batch; among equals the logic phases first (they feed the traversal), then
         //      leaves, then inner nodes ----
@@ -1476,7 +1517,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
                     if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
-                    if (__ballot(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
+                    if (__builtin_amdgcn_ballot_w64(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
                         if (ex) {
                             const float4 qb = S.B[id];
                             done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
@@ -1554,9 +1595,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             dg_lanes[PH3_LA] += (unsigned)take;
 #endif
             if (on) {
+                LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_A<MODE>(P, tb, g, S.A[id], S.B[id], nr, cnt, ALL);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
+                nph = logic_A<MODE>(Pl, tl, g, S.A[id], S.B[id], nr, cnt, ALL);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         } else if (act == PH3_LB) {
@@ -1565,9 +1607,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             dg_lanes[PH3_LB] += (unsigned)take;
 #endif
             if (on) {
+                LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_B<MODE>(P, g, S.A[id], S.B[id], nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
+                nph = logic_B<MODE>(Pl, g, S.A[id], S.B[id], nr);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         } else {
@@ -1576,8 +1619,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             dg_lanes[PH3_LC] += (unsigned)take;
 #endif
             if (on) {
+                LOGIC_PARAMS()
                 NewRay nr;
-                if (logic_C(P, tb, g, cnt, nr)) nph = start_ray<MODE>(sc, S, id, nr, cnt, M3.force_exact != 0);
+                if (logic_C(Pl, tl, g, cnt, nr)) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         }
@@ -1585,6 +1629,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
 #undef PUSH3
 #undef POP3
+#undef LOGIC_PARAMS
 
     // ---- counters ----
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths), un = wave_sum(cnt.untraced);
