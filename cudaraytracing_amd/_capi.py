@@ -89,7 +89,7 @@ LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
            "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_intersect",
-           "crt_device_math", "crt_device_philox", "crt_host_scene_create", "crt_host_scene_destroy",
+           "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_desc", "crt_host_scene_num_objects",
            "crt_host_scene_object", "crt_inverse_view", "crt_task_load", "crt_write_png"]
 
@@ -124,6 +124,7 @@ def lib():
     L.crt_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.crt_device_math.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crt_device_philox.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.crt_device_rcp_check.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.crt_host_scene_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
     L.crt_host_scene_destroy.argtypes = [C.c_void_p]
     L.crt_host_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]

@@ -282,6 +282,15 @@ def device_math(fn, a, b=None, device=0):
     return out
 
 
+def device_rcp_check(device=0):
+    """(mismatches inside the guarded range, mismatches outside it) of the kernels' short reciprocal against
+    the division 1.0f / x over all 2^32 inputs (crt_device_rcp_check)."""
+    import ctypes as C
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    capi.check(capi.lib().crt_device_rcp_check(device, C.byref(a), C.byref(b)), "crt_device_rcp_check")
+    return int(a.value), int(b.value)
+
+
 def device_philox(ctr, key, device=0):
     c = np.ascontiguousarray(ctr, dtype=np.uint32).reshape(-1, 4)
     k = np.ascontiguousarray(key, dtype=np.uint32).reshape(-1, 2)

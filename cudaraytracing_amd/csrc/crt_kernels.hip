@@ -939,6 +939,30 @@ __device__ __forceinline__ float fmax3(float a, float b, float c) { return __bui
 __device__ __forceinline__ v2f v2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ v2f v2s(float a) { v2f r; r.x = a; r.y = a; return r; }
 
+// 1.0f / x, bit for bit, in 3 instructions + a guard instead of the 12 of the IEEE division expansion: v_rcp_f32 and one
+// Newton step in FMA.  Verified EXHAUSTIVELY on gfx950 (tools/exhaustive/rcp_check.hip, all 2^32 inputs; crt_selftest()
+// repeats the check through the C ABI): the bits differ from the division's only for zero / denormal x, |x| >= 2^126
+// (denormal quotient) and infinities -- those lanes take the division itself behind a wave-uniform branch.
+__device__ __forceinline__ bool rcp_short_ok(const float x)
+{
+    const float ax = absf(x);
+    return (ax >= 0x1p-126f) & (ax < 0x1p126f); // exponent field in [1, 252]; false for NaN
+}
+__device__ __forceinline__ float rcp_short(const float x)
+{
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float rcp_ieee(const float x)
+{
+    float r = rcp_short(x);
+    const bool ok = rcp_short_ok(x);
+    if (__builtin_amdgcn_ballot_w64(!ok)) {
+        if (!ok) r = 1.0f / x;
+    }
+    return r;
+}
+
 // Ring index in [0, 2 * POOL3_QCAP) -> [0, POOL3_QCAP).
 __device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)POOL3_QCAP); }
 
@@ -956,7 +980,14 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     cnt.rays++;
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
     cnt.probe += (nr.flags & RF_PROBE) ? 1u : 0u;
-    const F3 inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z); // Ray.cuh:14
+    F3 inv = f3(rcp_short(nr.d.x), rcp_short(nr.d.y), rcp_short(nr.d.z)); // 1 / d (Ray.cuh:14), see rcp_ieee
+    {
+        asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z));
+        const bool ok = rcp_short_ok(nr.d.x) & rcp_short_ok(nr.d.y) & rcp_short_ok(nr.d.z);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+            if (!ok) inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z);
+        }
+    }
     uint32_t flags = nr.flags;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
@@ -1263,8 +1294,17 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     const v2f s1x = v2s(d.y) * e2z - v2s(d.z) * e2y, s1y = v2s(d.z) * e2x - v2s(d.x) * e2z, s1z = v2s(d.x) * e2y - v2s(d.y) * e2x;
     const v2f s2x = sy * e1z - sz * e1y, s2y = sz * e1x - sx * e1z, s2z = sx * e1y - sy * e1x;
     const v2f det = s1x * e1x + (s1y * e1y + s1z * e1z);
-    v2f rcp;
-    rcp.x = 1 / det.x; rcp.y = 1 / det.y;
+    v2f rcp; // 1 / det (DeviceTriangle.cuh:47), see rcp_ieee
+    {
+        v2f r0;
+        r0.x = __builtin_amdgcn_rcpf(det.x); r0.y = __builtin_amdgcn_rcpf(det.y);
+        rcp = __builtin_elementwise_fma(__builtin_elementwise_fma(-det, r0, v2s(1.0f)), r0, r0);
+        asm volatile("" : "+v"(rcp)); // (keeps the short form ahead of the branch instead of in an else-arm)
+        const bool ok = rcp_short_ok(det.x) & rcp_short_ok(det.y);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+            if (!ok) { rcp.x = 1 / det.x; rcp.y = 1 / det.y; }
+        }
+    }
     const v2f beta = (s1x * sx + (s1y * sy + s1z * sz)) * rcp;
     const v2f gamma = (s2x * v2s(d.x) + (s2y * v2s(d.y) + s2z * v2s(d.z))) * rcp;
     const v2f t = (s2x * e2x + (s2y * e2y + s2z * e2z)) * rcp;
@@ -1770,6 +1810,22 @@ __global__ void k_math(int fn, uint32_t n, const float* a, const float* b, float
     }
     out[i] = r;
 }
+// crt_device_rcp_check: every fp32 bit pattern through rcp_short and through the division
+__global__ void k_rcp_check(unsigned long long* counts)
+{
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned int bad_in = 0, bad_out = 0;
+    for (unsigned long long b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float ref = 1.0f / x, got = rcp_short(x);
+        const bool same = __float_as_uint(ref) == __float_as_uint(got) || (ref != ref && got != got);
+        if (!same) { if (rcp_short_ok(x)) bad_in++; else bad_out++; }
+    }
+    bad_in = wave_sum(bad_in); bad_out = wave_sum(bad_out);
+    if ((threadIdx.x & 63) == 0 && (bad_in | bad_out)) { atomicAdd(&counts[0], (unsigned long long)bad_in); atomicAdd(&counts[1], (unsigned long long)bad_out); }
+}
+
 __global__ void k_philox(uint32_t n, const uint32_t* ctr, const uint32_t* key, uint32_t* out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2728,6 +2784,26 @@ int crt_device_philox(int device, uint32_t n, const uint32_t* ctr4, const uint32
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(out4, o.p, n * 16ull, hipMemcpyDeviceToHost));
+        return CRT_OK;
+    } catch (const HipFail& f) {
+        return fail_hip(f);
+    }
+}
+
+int crt_device_rcp_check(int device, uint64_t* mismatches, uint64_t* outside)
+{
+    if (!mismatches || !outside) return fail(CRT_ERR_INVALID_ARG, "crt_device_rcp_check: null argument");
+    try {
+        HIP_CHECK(hipSetDevice(device));
+        DevBuf<unsigned long long> c;
+        c.alloc(2);
+        HIP_CHECK(hipMemset(c.p, 0, 2 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(k_rcp_check, dim3(256 * 32), dim3(256), 0, 0, c.p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+        unsigned long long h[2];
+        HIP_CHECK(hipMemcpy(h, c.p, sizeof(h), hipMemcpyDeviceToHost));
+        *mismatches = h[0]; *outside = h[1];
         return CRT_OK;
     } catch (const HipFail& f) {
         return fail_hip(f);

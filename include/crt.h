@@ -198,6 +198,11 @@ int crt_intersect(crt_scene* scene, uint32_t n, const float* origins, const floa
  * tests against the oracle.  fn in {"sin","cos","tan","acos","atan2","exp","log10","pow","uniform"}. */
 int crt_device_math(int device, const char* fn, uint32_t n, const float* a, const float* b, float* out);
 int crt_device_philox(int device, uint32_t n, const uint32_t* ctr4, const uint32_t* key2, uint32_t* out4);
+/* Exhaustive self-check of the short reciprocal the kernels use in place of the division 1.0f / x (Ray.cuh:14,
+ * DeviceTriangle.cuh:47): evaluates both for all 2^32 bit patterns of x on the device and returns, in *mismatches, the
+ * number of inputs INSIDE the guarded range (2^-126 <= |x| < 2^126) whose bits differ (must be 0), and in *outside the
+ * number of inputs outside the range that differ (those take the division itself).  A few milliseconds. */
+int crt_device_rcp_check(int device, uint64_t* mismatches, uint64_t* outside);
 
 /* ------------------------------------------------------------------------
  * Host layer: scene ingestion and BVH build on the CPU (north star: "C++ host

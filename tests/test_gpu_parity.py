@@ -60,6 +60,14 @@ def test_device_math_two_arg_and_uniform():
     assert got.min() > 0.0 and got.max() <= 1.0
 
 
+def test_short_reciprocal_is_the_division_for_every_input():
+    # the kernels compute 1/det and 1/direction as v_rcp_f32 + one Newton step in FMA; inside the guarded exponent range the
+    # bits must equal those of the IEEE division for ALL inputs (outside it the kernels take the division itself)
+    inside, outside = crt.device_rcp_check()
+    assert inside == 0
+    assert outside > 0  # (zero / denormal / huge / infinite inputs do differ: the guard is not vacuous)
+
+
 def test_device_philox_matches_oracle_and_kat():
     ctr = np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32)
     key = np.array([[0, 0], [0xFFFFFFFF] * 2, [0xA4093822, 0x299F31D0]], dtype=np.uint32)
