@@ -44,16 +44,23 @@ def untile_torch(gathered, width, height):
     return a[:height, :width].contiguous()
 
 
+_hip_runtime_checked = False
+
+
 def _check_single_hip_runtime():
     """torch bundles its own libamdhip64.so.7; libcrt.so links the system one.  The loader
     shares one copy only if torch is imported BEFORE libcrt.so is loaded (it matches the
     request against the SONAME of what is already mapped).  Two HIP runtimes in one process
     cannot see each other's allocations, so refuse to continue."""
+    global _hip_runtime_checked
+    if _hip_runtime_checked:  # (once per process: libcrt.so and torch are both loaded by the time of the first frame)
+        return
     paths = set()
     with open("/proc/self/maps") as f:
         for line in f:
             if "libamdhip64" in line:
                 paths.add(line.split()[-1])
+    _hip_runtime_checked = len(paths) <= 1
     if len(paths) > 1:
         raise RuntimeError("two HIP runtimes are mapped (%s): import torch before using cudaraytracing_amd"
                            % ", ".join(sorted(paths)))
