@@ -87,6 +87,8 @@ struct LParams {
     uint32_t width, height;
     float p_rr;
     int32_t lsn;
+    float inv_lsn_pow2;     // 1 / lsn when lsn is a power of two (x / 2^k and x * 2^-k round the same real number: same bits), else 0
+    uint32_t pad_;
     uint64_t seed;
     uint32_t rank, world, tiles_x, n_tiles;
     uint32_t nslots;        // pixel slots of this shard (local tiles * 64)
@@ -230,7 +232,8 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
     c = scale3(c, cos_theta_2);
     c = scale3(c, l3.w);
     c = div3(c, t2);
-    c = div3(c, (float)P.lsn);
+    if (P.inv_lsn_pow2 != 0.0f) c = scale3(c, P.inv_lsn_pow2); // == c / lsn bit for bit (LParams)
+    else c = div3(c, (float)P.lsn);
     s.c = c;
 }
 
@@ -248,15 +251,33 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
         float4 a = pl.rec_a[(size_t)deepest * pl.n + slot];
         L = add3(f3(0.0f, 0.0f, 0.0f), f3(a.x, a.y, a.z)); // final hit: direct light only (:316-319)
     }
-    for (int v = deepest - 1; v >= 0; v--) {
-        float4 a = pl.rec_a[(size_t)v * pl.n + slot];
-        uint32_t mat = __float_as_uint(pl.rec_b[(size_t)v * pl.n + slot].w);
-        float4 fm = mat_row(tb, mat, 0);
-        F3 ind = mul3(L, f3(fm.x, fm.y, fm.z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
-        ind = scale3(ind, a.w);
-        ind = scale3(ind, inv_pdf_sphere);
-        ind = div3(ind, P.p_rr);
-        L = add3(ind, f3(a.x, a.y, a.z)); // :323
+    // The recursion is a serial chain, but its loads are not: the records (and material rows) of CRT_FINISH_PF vertices are
+    // fetched together, so a chunk costs two memory round trips instead of two per vertex (lanes with fewer vertices re-read
+    // vertex 0 and skip the arithmetic).
+#ifndef CRT_FINISH_PF
+#define CRT_FINISH_PF 4
+#endif
+    for (int v = deepest - 1; v >= 0; v -= CRT_FINISH_PF) {
+        float4 a[CRT_FINISH_PF], fm[CRT_FINISH_PF];
+        uint32_t mat[CRT_FINISH_PF];
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) {
+            const int vj = v - j > 0 ? v - j : 0;
+            a[j] = pl.rec_a[(size_t)vj * pl.n + slot];
+            mat[j] = __float_as_uint(pl.rec_b[(size_t)vj * pl.n + slot].w);
+        }
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) fm[j] = mat_row(tb, mat[j], 0);
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) {
+            if (v - j >= 0) {
+                F3 ind = mul3(L, f3(fm[j].x, fm[j].y, fm[j].z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
+                ind = scale3(ind, a[j].w);
+                ind = scale3(ind, inv_pdf_sphere);
+                ind = div3(ind, P.p_rr);
+                L = add3(ind, f3(a[j].x, a[j].y, a[j].z)); // :323
+            }
+        }
     }
     return L;
 }
@@ -2042,6 +2063,9 @@ Shard make_shard(uint32_t w, uint32_t h, uint32_t world)
     return s;
 }
 
+// 1 / n for n a power of two (exactly representable), else 0
+float inv_if_pow2(int32_t n) { return (n > 0 && (n & (n - 1)) == 0) ? 1.0f / (float)n : 0.0f; }
+
 uint32_t env_u32(const char* name, uint32_t dflt)
 {
     const char* v = std::getenv(name);
@@ -2201,7 +2225,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
             P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
             P.nslots = sh.nslots;
-            P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
+            P.inv_lsn_pow2 = inv_if_pow2(prm->light_sample_n); P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
             P.L = sc->L.p; P.counters = sc->counters.p; P.item_next = sc->item_next.p; P.n_mats = sc->n_mats;
             M.sc = sc->dev; M.counters = sc->counters.p; M.spill = sc->spill[0].p; M.spill_stride = lanes; M.stack_cap = lds_cap;
             AParams A;
@@ -2308,7 +2332,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         P.p_rr = prm->p_rr; P.lsn = prm->light_sample_n; P.seed = prm->seed;
         P.rank = prm->rank; P.world = prm->world; P.tiles_x = sh.tiles_x; P.n_tiles = sh.n_tiles;
         P.nslots = sh.nslots;
-        P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
+        P.inv_lsn_pow2 = inv_if_pow2(prm->light_sample_n); P.lsn_div = make_fastdiv((uint32_t)std::max(1, prm->light_sample_n)); P.nslots_div = make_fastdiv(sh.nslots); P.tiles_x_div = make_fastdiv(sh.tiles_x);
         P.L = sc->L.p;
         P.counters = sc->counters.p;
         P.item_next = sc->item_next.p;
