@@ -922,6 +922,7 @@ struct MParams {
 #define RF_PROBE 0x8000000u    /* SPECULAR emitter probe */
 #define RF_EXACT 0x10000000u   /* reference box arithmetic (non-finite operands) */
 #define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
+#define RF_SKIP 0x40000000u    /* (NewRay only) next-event sample with a zero contribution: answered without traversal */
 #ifndef POOL3_P
 #define POOL3_P 148         /* 148 x 64 B + rings = 10 212 B: 16 waves per CU */
 #endif
@@ -1009,7 +1010,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
             if (!ok) inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z);
         }
     }
-    uint32_t flags = nr.flags;
+    uint32_t flags = nr.flags & ~RF_SKIP;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
     const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX; // a finite 1/d has a finite d
@@ -1023,7 +1024,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
         flags |= RF_ANYHIT;
         T = nr.tl;
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
-        answered = !(nr.tl == nr.tl) || nr.tl == -pinf();
+        answered = !(nr.tl == nr.tl) || nr.tl == -pinf() || (nr.flags & RF_SKIP) != 0;
     }
     S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, T);
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
@@ -1158,11 +1159,21 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // whatever the ray finds -- L_dir is never -0 -- so the FAST traversal answers the sample without tracing it.  It still
     // counts as a ray of the reference (`rays`, `shadow_rays`); `rays_untraced` says how many there were.  A NaN contribution
     // fails the comparison and is traced.  (CRT_TRAVERSAL_REFERENCE traces everything: its counters are the reference's visit set.)
+    // The next sample of such a lane is set up right here while enough lanes of the batch need it (setup_shadow is the most
+    // expensive section of the phase and the others wait); the last few stragglers are instead handed to start_ray as
+    // "answered" (RF_SKIP) and go back to the ring of their consumer, which adds the zero contribution.
+#ifndef LA_LOOP_MIN
+#define LA_LOOP_MIN 16
+#endif
     const float4 m0 = mat_row(tb, s.mat, 0);
+    bool skip;
     for (;;) {
         setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
-        if (MODE == 1 || trace_all || !(s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f)) break;
-        cnt.rays++; cnt.shadow++; cnt.untraced++;
+        skip = MODE == 0 && !trace_all && (s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f);
+        if (!skip) break;
+        cnt.untraced++;
+        if (__popcll(__builtin_amdgcn_ballot_w64(true)) < LA_LOOP_MIN) break; // (the lanes still in the loop are the ones that skip)
+        cnt.rays++; cnt.shadow++;
         s.q++;
         if (s.q == (uint32_t)(sc.n_lights * P.lsn)) { // that was the last sample of the vertex: on to the roulette
             pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
@@ -1172,7 +1183,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
     pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, s.tl);
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
-    nr.flags = RF_SHADOW | (s.q + 1 == (uint32_t)(sc.n_lights * P.lsn) ? RF_LAST : 0u);
+    nr.flags = RF_SHADOW | (s.q + 1 == (uint32_t)(sc.n_lights * P.lsn) ? RF_LAST : 0u) | (skip ? RF_SKIP : 0u);
     return PH3_NONE;
 }
 
