@@ -316,6 +316,13 @@ def test_leaf_of_300_triangles(tmp_path):
     assert st["rays"] > 5000
 
 
+def test_room_of_180000_triangles(tmp_path):
+    """A floor tessellated into 180 000 triangles (node / triangle indices beyond 16 bits, an 18-level reference tree,
+    traversal stacks far beyond the three LDS levels)."""
+    st = _compare_room(tmp_path, 2, lsn=1, p_rr=0.6, spp=1, n_side=300, w=40, h=30)
+    assert st["rays"] > 3000
+
+
 @pytest.mark.parametrize("specular", [False, True])
 def test_rays_with_non_finite_operands_take_the_reference_arithmetic(tmp_path, specular):
     """CRT_FLAG_FORCE_EXACT sends every ray of the FAST traversal down the path that rays with a zero / denormal direction
