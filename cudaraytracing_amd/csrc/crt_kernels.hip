@@ -198,13 +198,10 @@ __device__ __forceinline__ float4 mat_row(const Tables<LDS_TABLES>& tb, uint32_t
 
 // Sets up next-event sample q of the current vertex: Render.cuh:262-272 (+ :274-283 evaluated
 // ahead of the visibility test; the value is only added if the shadow ray is not blocked).
-template <bool LDS_TABLES>
-__device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_TABLES>& tb, Lane& s, F3 f_r)
+// lg = lights[q / lsn] (sample q = light li, repetition sj; the draw index li * lsn + sj is q itself), loaded by the caller.
+__device__ __forceinline__ void setup_shadow_lg(const LParams& P, Lane& s, F3 f_r, const uint4 lg)
 {
     const DevScene& sc = P.sc;
-    // sample q = light li, repetition sj; the draw index li * lsn + sj is q itself
-    const uint32_t li = fast_div(s.q, P.lsn_div.m, P.lsn_div.sh);
-    const uint4 lg = tb.lights[li];
     U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, s.q);
     const uint32_t ti = rl.x - fast_div(rl.x, lg.z, lg.w) * lg.y; // rand % triangle count (DeviceLights.cuh:35)
     const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
@@ -235,6 +232,11 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
     if (P.inv_lsn_pow2 != 0.0f) c = scale3(c, P.inv_lsn_pow2); // == c / lsn bit for bit (LParams)
     else c = div3(c, (float)P.lsn);
     s.c = c;
+}
+template <bool LDS_TABLES>
+__device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_TABLES>& tb, Lane& s, F3 f_r)
+{
+    setup_shadow_lg(P, s, f_r, tb.lights[fast_div(s.q, P.lsn_div.m, P.lsn_div.sh)]);
 }
 
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
@@ -1053,13 +1055,29 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
 {
     const DevScene& sc = P.sc;
     const Pool& pl = P.pool;
+    // The phase is a chain of dependent loads (path planes -> triangle / material / light tables -> light triangle), and a wave
+    // that waits issues nothing: everything whose address is known is fetched up front, needed by this lane's stage or not.
+    //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
     const float4 la = pl.la[g];
     const uint4 idv = pl.id[g];
     const float4 vn = pl.vn[g];
-    const uint32_t st = __float_as_uint(la.w);
-    const uint32_t stage = (st >> 8) & 15u;
+    const float4 cc = pl.cc[g]; // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
     const int res_tri = __float_as_int(qb.w);
+    const float4 gq_hit = sc.tri_nm[res_tri >= 0 ? res_tri : 0];
+    const uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = (st >> 8) & 15u;
+    //   round 2: material rows of the vertex the samples belong to after this visit (the new one for ST_HIT), row 1 of the
+    //   vertex the ray left (specular flag, ST_HIT), and the light of the sample that is set up below
+    //   (the vn plane of a slot's very first vertex has never been written: the speculative index is clamped into the table)
+    const uint32_t mat_old = min(__float_as_uint(vn.w), P.n_mats - 1u);
+    const uint32_t mat_cur = stage == ST_HIT ? __float_as_uint(gq_hit.w) : mat_old;
+    float4 m0_cur = mat_row(tb, mat_cur, 0), m1_cur = mat_row(tb, mat_cur, 1);
+    const float4 pm1_old = mat_row(tb, mat_old, 1);
+    const uint32_t n_nee = (uint32_t)(sc.n_lights * P.lsn);
+    const uint32_t q_next = stage == ST_SHADOW ? (st >> 16) + 1 : 0u;
+    uint4 lg_next = make_uint4(0u, 1u, 0u, 0u);
+    if (n_nee > 0) lg_next = tb.lights[fast_div(q_next < n_nee ? q_next : 0u, P.lsn_div.m, P.lsn_div.sh)];
     Lane s;
     s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
     s.Ld = f3(la.x, la.y, la.z);
@@ -1071,7 +1089,6 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     bool do_enter = false;
     if (stage == ST_SHADOW) {
         // visibility of next-event sample q (Render.cuh:19-27, :272-284); shadow rays start at the vertex: s.pos == s.ro
-        const float4 cc = pl.cc[g]; // .w = distance to the light sample
         if (!shadow_blocked<MODE>(cc.w, res_t, res_tri)) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
         s.q++;
     } else if (stage == ST_HIT) {
@@ -1085,8 +1102,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
             cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
             pl.rec_a[pr].w = cos_prev;
-            const float4 pm1 = mat_row(tb, s.mat, 1);
-            if (__float_as_uint(pm1.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
+            if (__float_as_uint(pm1_old.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
                 const float ns = mat_row(tb, s.mat, 0).w;
                 const float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
                 const float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
@@ -1135,20 +1151,23 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         do_enter = true;
     }
     if (do_enter) { // a new vertex (pos, vtri) at `depth`, reached along s.rd
-        const float4 gq = sc.tri_nm[s.vtri];
+        float4 gq = gq_hit;
+        if (stage == ST_PROBE) { // the vertex was found by the ray before the probe: its triangle waits in the vx plane
+            gq = sc.tri_nm[s.vtri];
+            m0_cur = mat_row(tb, __float_as_uint(gq.w), 0); m1_cur = mat_row(tb, __float_as_uint(gq.w), 1);
+        }
         s.nrm = f3(gq.x, gq.y, gq.z);
         s.mat = __float_as_uint(gq.w);
         pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
         pl.vx[g] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
         pl.vn[g] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
-        const float4 m1 = mat_row(tb, s.mat, 1);
-        if (__float_as_uint(m1.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+        if (__float_as_uint(m1_cur.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
             pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16)));
             return PH3_LC;
         }
         s.Ld = f3(0.0f, 0.0f, 0.0f);
         s.q = 0;
-        if (sc.n_lights * P.lsn <= 0) {
+        if (n_nee == 0) {
             pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
             return PH3_LB;
         }
@@ -1165,17 +1184,18 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
 #ifndef LA_LOOP_MIN
 #define LA_LOOP_MIN 16
 #endif
-    const float4 m0 = mat_row(tb, s.mat, 0);
+    const float4 m0 = m0_cur;
     bool skip;
-    for (;;) {
-        setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
+    for (bool first = true;; first = false) {
+        if (first) setup_shadow_lg(P, s, f3(m0.x, m0.y, m0.z), lg_next); // (s.q == q_next: the light entry is already here)
+        else setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
         skip = MODE == 0 && !trace_all && (s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f);
         if (!skip) break;
         cnt.untraced++;
         if (__popcll(__builtin_amdgcn_ballot_w64(true)) < LA_LOOP_MIN) break; // (the lanes still in the loop are the ones that skip)
         cnt.rays++; cnt.shadow++;
         s.q++;
-        if (s.q == (uint32_t)(sc.n_lights * P.lsn)) { // that was the last sample of the vertex: on to the roulette
+        if (s.q == n_nee) { // that was the last sample of the vertex: on to the roulette
             pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
             return PH3_LB;
         }
@@ -1183,7 +1203,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
     pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, s.tl);
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
-    nr.flags = RF_SHADOW | (s.q + 1 == (uint32_t)(sc.n_lights * P.lsn) ? RF_LAST : 0u) | (skip ? RF_SKIP : 0u);
+    nr.flags = RF_SHADOW | (s.q + 1 == n_nee ? RF_LAST : 0u) | (skip ? RF_SKIP : 0u);
     return PH3_NONE;
 }
 
