@@ -47,8 +47,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)  # (the first two frames after start-up run 1 % slower: clocks and caches settle)
     ap.add_argument("--scene", default="cornell-box")
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--height", type=int, default=600)
