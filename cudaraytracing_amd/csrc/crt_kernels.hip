@@ -1214,12 +1214,12 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     const Pool& pl = P.pool;
     const float4 la = pl.la[g];
     const uint4 idv = pl.id[g];
+    const float4 cc = pl.cc[g]; // (with the other planes, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     uint32_t depth = st & 255u;
     F3 Ld = f3(la.x, la.y, la.z);
     if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
-        const float4 cc = pl.cc[g];
         if (!shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w))) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
     pl.rec_a[(size_t)depth * pl.n + g] = make_float4(Ld.x, Ld.y, Ld.z, 0.0f);
@@ -1248,11 +1248,11 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
 {
     const Pool& pl = P.pool;
     const float4 la = pl.la[g];
+    const uint4 idv = pl.id[g]; // (with la, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
     if (stage != ST_NEW) {
-        const uint4 idv = pl.id[g];
         int deepest = (int)depth;
         bool emissive = false;
         F3 ke = f3(0.0f, 0.0f, 0.0f);
