@@ -2105,7 +2105,7 @@ uint32_t env_u32(const char* name, uint32_t dflt)
     return x > 0 ? (uint32_t)x : dflt;
 }
 
-const uint64_t kMaxChunkItems = 1ull << 28; // paths per chunk (4.3 GB of per-path radiance)
+const uint64_t kMaxChunkItems = 1ull << 30; // paths per chunk (17 GB of per-path radiance: sized for 288 GB of HBM, every launch ends with a 2 ms tail)
 
 template <int MODE, bool STATS> void launch_trace(const TParams& T, uint32_t blocks, size_t lds, hipStream_t st)
 {
@@ -2183,7 +2183,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
     try {
         HIP_CHECK(hipSetDevice(sc->device));
         Shard sh = make_shard(prm->width, prm->height, prm->world);
-        uint32_t chunk = (uint32_t)std::min<uint64_t>(s_count, std::max<uint64_t>(1, kMaxChunkItems / sh.nslots));
+        const uint64_t max_items = std::min<uint64_t>(kMaxChunkItems, 1ull << std::min(30u, env_u32("CRT_CHUNK_LOG2", 30))); // (test hook: small chunks)
+        uint32_t chunk = (uint32_t)std::min<uint64_t>(s_count, std::max<uint64_t>(1, max_items / sh.nslots));
         uint64_t cap = (uint64_t)chunk * sh.nslots;
         const uint32_t pool_log2 = std::min(26u, std::max(8u, env_u32("CRT_POOL_LOG2", 22)));
         const uint32_t pool_n = (uint32_t)std::min<uint64_t>((cap + 255) / 256 * 256, 1ull << pool_log2);

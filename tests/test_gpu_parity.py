@@ -394,6 +394,27 @@ def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
         r.run_view_range(eye, iv, fov, 5, 3, width=96, height=72)   # beyond spp
 
 
+@pytest.mark.parametrize("pipeline", ["2", "4"])
+def test_samples_rendered_in_chunks_equal_one_launch(renders, pipeline, monkeypatch):
+    """Frames with more work items than the per-item radiance buffer holds are rendered in chunks of samples (one launch each)
+    that accumulate in sample order: forced here with a tiny buffer (7 samples -> 4 launches)."""
+    monkeypatch.setenv("CRT_PIPELINE", pipeline)
+    name = "cornell-box"
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.set_spp(7)
+    r.traversal = crt.TRAVERSAL_FAST
+    one = r.run_view(eye, iv, fov, width=64, height=48).copy()
+    mean_one = r.mean_buffer.copy()
+    launches_one = r.stats["kernel_launches"]
+    monkeypatch.setenv("CRT_CHUNK_LOG2", "13")  # 8192 items: two samples of 64 x 48 pixels per launch
+    many = r.run_view(eye, iv, fov, width=64, height=48)
+    assert np.array_equal(util.bits(r.mean_buffer), util.bits(mean_one))
+    assert np.array_equal(many, one)
+    if pipeline == "4":
+        assert launches_one == 1 and r.stats["kernel_launches"] == 4
+
+
 def test_zero_contribution_samples_are_answered_without_traversal(renders):
     """FAST answers next-event samples whose contribution is exactly zero without tracing them (adding +0 cannot change L_dir):
     same frame, same reference ray counts, with and without CRT_FLAG_TRACE_ALL; REFERENCE traces everything."""
