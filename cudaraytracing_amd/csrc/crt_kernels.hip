@@ -898,7 +898,7 @@ struct MParams {
 //       LC  path ends (miss / emitter / roulette) -> backward recursion, next work item, camera ray
 //     the traversal step routes a finished ray from flag bits in its LDS record; a phase that finds the
 //     path belongs elsewhere (emitter found in LA, roulette stop in LB) parks it there without a ray.
-//   * 1/direction lives in the LDS record (76 B per ray: origin, direction, 1/direction, one distance,
+//   * 1/direction lives in the LDS record (64 B per ray: origin, direction, 1/direction, one distance,
 //     best triangle, node, flags, 3 stack levels, ring slots), so the inner step has no divisions;
 //   * inner nodes are stored as (left, right) PAIRS per coordinate, so that both child boxes go through
 //     v_pk_add_f32 / v_pk_mul_f32 together; rays whose origin, direction and 1/direction are all finite
@@ -1395,7 +1395,7 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
 }
 
 // One step at a node of the 4-wide tree (rays with finite operands, CRT_TRAVERSAL_FAST): four child boxes as two packed pairs,
-// the nearest hit child next, the others pushed farthest first with their entry distances.  Which children are visited, and in
+// the nearest hit child next, the others pushed farthest first.  Which children are visited, and in
 // which order, does not change the result (crt_trace.h); the boxes and the test are the reference's (hit_AABB with minima /
 // maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, class LDS>
@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         dg_iter[act]++;
 #endif
         if (act == PH3_INNER) {
-            // ---- inner-node step: both child boxes, near child next, far child pushed with its entry distance ----
+            // ---- inner-node step: the child boxes, nearest child next, the other hit children pushed ----
 #ifdef CRT_STAMPS
             dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
