@@ -323,6 +323,73 @@ def test_room_of_180000_triangles(tmp_path):
     assert st["rays"] > 3000
 
 
+def _write_soup_scene(d, n=400, dup=60, degenerate=20, seed=11):
+    """A closed room with a light and, inside it, a soup of random triangles: `dup` of them twice with identical vertices (equal
+    hit distances in different leaves: the reference's tie rule), `degenerate` with zero area (determinant 0: the division by it
+    is the IEEE one, not the short reciprocal), and coplanar overlapping quads."""
+    import os
+    rng = np.random.RandomState(seed)
+    obj, mtl = _write_box_scene(d, n_side=4)
+    tris = []
+    for _ in range(n):
+        c = rng.uniform(1.5, 8.5, 3)
+        tris.append(c + rng.uniform(-0.9, 0.9, (3, 3)))
+    for i in rng.choice(n, dup, replace=False):
+        tris.append(tris[i].copy())                       # exact duplicates
+    for _ in range(degenerate):
+        p, q = rng.uniform(2, 8, 3), rng.uniform(2, 8, 3)
+        tris.append(np.stack([p, q, p + 0.5 * (q - p)]))  # collinear vertices
+    for z in (3.0, 3.0, 6.0):                             # coplanar overlapping quads (two of them in the same plane)
+        x0, y0 = rng.uniform(2, 5, 2)
+        tris.append(np.array([[x0, y0, z], [x0 + 3, y0, z], [x0 + 3, y0 + 3, z]]))
+        tris.append(np.array([[x0, y0, z], [x0 + 3, y0 + 3, z], [x0, y0 + 3, z]]))
+    with open(obj) as f:
+        nv = sum(1 for line in f if line.startswith("v "))
+    with open(obj, "a") as o:
+        o.write("usemtl floor\n")
+        for t in tris:
+            for v in t.astype(np.float32):
+                o.write("v %.9g %.9g %.9g\nvn 0 1 0\nvt 0 0\n" % tuple(v))
+            o.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (nv + 1, nv + 1, nv + 1, nv + 2, nv + 2, nv + 2, nv + 3, nv + 3, nv + 3))
+            nv += 3
+    return obj, mtl
+
+
+@pytest.mark.parametrize("thresh", [1, 2, 4])
+def test_triangle_soup_with_ties_and_degenerate_triangles(tmp_path, thresh):
+    obj, mtl = _write_soup_scene(str(tmp_path))
+    w, h, spp = 64, 48, 2
+    scene = crt.Scene(w, h)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(thresh)
+    osc = O.OracleScene([(obj, mtl)], thresh)
+    assert scene.nodes().tobytes() == osc.nodes().tobytes()
+    eye = np.array([5.0, 5.0, 0.5], dtype=np.float32)
+    iv = crt.get_inverse_view_matrix(eye, [5.0, 4.5, 9.0], [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, spp, 0.6, 2)
+    r.seed = 5
+    orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
+    try:
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), mode
+            assert np.array_equal(rgb, orgb)
+            assert r.stats["rays"] == st["rays"]
+        # closest-hit queries straight at the duplicated / coplanar triangles: triangle ids must agree, not only distances
+        n = 4096
+        rng = np.random.RandomState(1)
+        o = np.tile(eye, (n, 1)).astype(np.float32)
+        dd = (rng.uniform([1.5, 1.5, 9.0], [8.5, 8.5, 9.0], (n, 3)) - eye).astype(np.float32)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            tri, t = r.intersect(o, dd, traversal=mode)
+            otri, ot, _ = osc.intersect(o, dd)
+            assert np.array_equal(tri, otri) and np.array_equal(util.bits(t), util.bits(ot)), mode
+    finally:
+        r.free()
+
+
 @pytest.mark.parametrize("specular", [False, True])
 def test_rays_with_non_finite_operands_take_the_reference_arithmetic(tmp_path, specular):
     """CRT_FLAG_FORCE_EXACT sends every ray of the FAST traversal down the path that rays with a zero / denormal direction
