@@ -390,6 +390,41 @@ def test_triangle_soup_with_ties_and_degenerate_triangles(tmp_path, thresh):
         r.free()
 
 
+@pytest.mark.parametrize("scale", [1e-12, 1e12, 1e17])
+def test_extreme_coordinate_scales(tmp_path, scale):
+    """The soup scene with every coordinate scaled: products underflow to denormals / overflow to inf, NaNs appear in the
+    radiance (1e12) -- kernel and oracle must still agree bit for bit (the NaNs included), in both traversal modes."""
+    obj, mtl = _write_soup_scene(str(tmp_path), n=200, dup=20, degenerate=10)
+    lines = open(obj).read().split("\n")
+    with open(obj, "w") as f:
+        for line in lines:
+            if line.startswith("v "):
+                x, y, z = (np.float32(float(v) * scale) for v in line.split()[1:4])
+                line = "v %.9g %.9g %.9g" % (x, y, z)
+            f.write(line + "\n")
+    w, h, spp = 48, 36, 2
+    scene = crt.Scene(w, h)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(2)
+    osc = O.OracleScene([(obj, mtl)], 2)
+    assert scene.nodes().tobytes() == osc.nodes().tobytes()
+    eye = (np.array([5.0, 5.0, 0.5]) * scale).astype(np.float32)
+    iv = crt.get_inverse_view_matrix(eye, (np.array([5.0, 4.5, 9.0]) * scale).astype(np.float32), [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, spp, 0.6, 2)
+    r.seed = 5
+    orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
+    try:
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (scale, mode)
+            assert np.array_equal(rgb, orgb)
+            assert r.stats["rays"] == st["rays"]
+    finally:
+        r.free()
+
+
 @pytest.mark.parametrize("specular", [False, True])
 def test_rays_with_non_finite_operands_take_the_reference_arithmetic(tmp_path, specular):
     """CRT_FLAG_FORCE_EXACT sends every ray of the FAST traversal down the path that rays with a zero / denormal direction
