@@ -1494,6 +1494,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     TravCounters tc;
     tc.inner = tc.leaf = tc.tests = tc.hits = 0;
     uint32_t max_sp = 0;
+#ifdef CRT_EXIT_HIST
+    const unsigned long long xh_t0 = wall_clock64();
+#endif
 #ifdef CRT_STAMPS
     unsigned long long dg_cyc[PH3_N + 1] = {0, 0, 0, 0, 0, 0};
     unsigned dg_iter[PH3_N] = {0, 0, 0, 0, 0}, dg_lanes[PH3_N] = {0, 0, 0, 0, 0};
@@ -1723,6 +1726,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #undef POP3
 #undef LOGIC_PARAMS
 
+#ifdef CRT_EXIT_HIST
+    if (lane == 0) { // histogram of wave lifetimes in CRT_EXIT_HIST-microsecond buckets (wall_clock64: 100 MHz)
+        unsigned long long b_ = (wall_clock64() - xh_t0) / (100ull * CRT_EXIT_HIST);
+        if (b_ > 19) b_ = 19;
+        atomicAdd(&M.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + C_DIAG + b_], 1ull);
+    }
+#endif
     // ---- counters ----
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths), un = wave_sum(cnt.untraced);
     unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
