@@ -113,6 +113,42 @@ def test_png_reader_rejects_what_it_does_not_support(tmp_path):
         crt.Scene(8, 8).add_obj(obj, mtl)
 
 
+@pytest.mark.parametrize("kind,w,h", [("rgb", 9, 7), ("palette4", 9, 7), ("rgb_big_filtered", 64, 48)])
+def test_damaged_png_files_are_decoded_or_rejected(tmp_path, kind, w, h):
+    """Random damage to a valid PNG (flipped bytes, truncation, inserted bytes, overwritten length / CRC words): the reader
+    returns an image or an error, it never reads out of bounds (a crash would take the test process down)."""
+    import random
+    random.seed(7)
+    d = str(tmp_path)
+    obj, mtl = _write_scene(d, kind, w, h)[:2]
+    png = os.path.join(d, "tex.png")
+    orig = open(png, "rb").read()
+    decoded = rejected = 0
+    for it in range(160):
+        b = bytearray(orig)
+        mode = it % 4
+        if mode == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode == 1:
+            b = b[:random.randrange(1, len(b))]
+        elif mode == 2:
+            i = random.randrange(8, len(b))
+            b[i:i] = bytes(random.randrange(256) for _ in range(random.randint(1, 16)))
+        else:
+            i = random.randrange(8, len(b) - 4)
+            b[i:i + 4] = random.getrandbits(32).to_bytes(4, "big")
+        with open(png, "wb") as f:
+            f.write(bytes(b))
+        try:
+            sc = crt.Scene(8, 8)
+            sc.add_obj(obj, mtl)
+            decoded += 1
+        except crt.CrtError:
+            rejected += 1
+    assert decoded + rejected == 160 and rejected > 40
+
+
 @pytest.mark.gpu
 def test_textured_scene_renders_like_oracle(tmp_path):
     obj, mtl = _write_scene(str(tmp_path), "rgb", 16, 16)
