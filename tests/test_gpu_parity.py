@@ -3,6 +3,8 @@
 Bar: bit-exact on the float mean-radiance buffer (the north star allows 1e-5; the
 design makes it exact, so the tests assert exact and report max |delta|), exact RGB8.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -216,6 +218,33 @@ def test_cli_renders_config_to_png(tmp_path):
     assert np.array_equal(np.asarray(Image.open(out)), orgb)
     bad = subprocess.run([cli, str(tmp_path / "missing.json")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "unable to open config" in bad.stderr
+
+
+def test_bench_with_two_ranks_on_one_device(renders, tmp_path):
+    """The N > 1 path of bench.py -- one process per rank, sharded render, all-gather, max-over-ranks timing, rank 0's JSON
+    line -- with both ranks on this box's one GPU over gloo (CRT_BENCH_ONE_DEVICE: RCCL refuses two ranks on a device).
+    The ranks' ray counts must add up to the whole frame's, and the gathered image must be the one-GPU image."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    png = str(tmp_path / "two.png")
+    env = dict(os.environ, CRT_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "4",
+           "--width", "200", "--height", "152", "--no-cpu-baseline", "--save-png", png]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=util.ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "strong"
+    name = "cornell-box"
+    eye, iv, fov = util.camera(name)
+    one = renders[name]
+    one.set_spp(4)
+    one.traversal = crt.TRAVERSAL_FAST
+    rgb = one.run_view(eye, iv, fov, width=200, height=152)
+    assert line["rays_per_frame"] == one.stats["rays"]
+    assert np.array_equal(np.asarray(Image.open(png)), rgb)
 
 
 def test_errors_are_reported_not_printed(renders):
