@@ -1361,8 +1361,14 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
     const v2f gamma = (s2x * v2s(d.x) + (s2y * v2s(d.y) + s2z * v2s(d.z))) * rcp;
     const v2f t = (s2x * e2x + (s2y * e2y + s2z * e2z)) * rcp;
     const v2f alpha = v2s(1.0f) - beta - gamma;
-    a0 = (0 < alpha.x) & (alpha.x < 1) & (0 < beta.x) & (beta.x < 1) & (0 < gamma.x) & (gamma.x < 1) & (t.x > CRT_EPSILON);
-    a1 = (0 < alpha.y) & (alpha.y < 1) & (0 < beta.y) & (beta.y < 1) & (0 < gamma.y) & (gamma.y < 1) & (t.y > CRT_EPSILON);
+    // inside(): 0 < alpha, beta, gamma < 1, each comparison false for a NaN.  v_minimum3_f32 / v_maximum3_f32 (IEEE 754-2019
+    // minimum / maximum) return NaN if any operand is one, so two comparisons on them are the same six (and -0 fails "0 <" either way).
+    const float lo0 = __builtin_elementwise_minimum(__builtin_elementwise_minimum(alpha.x, beta.x), gamma.x);
+    const float hi0 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(alpha.x, beta.x), gamma.x);
+    const float lo1 = __builtin_elementwise_minimum(__builtin_elementwise_minimum(alpha.y, beta.y), gamma.y);
+    const float hi1 = __builtin_elementwise_maximum(__builtin_elementwise_maximum(alpha.y, beta.y), gamma.y);
+    a0 = (0 < lo0) & (hi0 < 1) & (t.x > CRT_EPSILON);
+    a1 = (0 < lo1) & (hi1 < 1) & (t.y > CRT_EPSILON);
     t0 = t.x; t1 = t.y;
 }
 
