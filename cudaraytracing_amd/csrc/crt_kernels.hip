@@ -972,6 +972,24 @@ __device__ __forceinline__ bool rcp_short_ok(const float x)
     const float ax = absf(x);
     return (ax >= 0x1p-126f) & (ax < 0x1p126f); // exponent field in [1, 252]; false for NaN
 }
+// the same guard for two / three values at once: IEEE 754-2019 minimum / maximum (v_minimum3_f32 / v_maximum3_f32) return NaN
+// if any operand is one, and a NaN fails both comparisons
+__device__ __forceinline__ bool rcp_short_ok2(const float x, const float y)
+{
+    const float ax = absf(x), ay = absf(y);
+    return (__builtin_elementwise_minimum(ax, ay) >= 0x1p-126f) & (__builtin_elementwise_maximum(ax, ay) < 0x1p126f);
+}
+__device__ __forceinline__ bool rcp_short_ok3(const float x, const float y, const float z)
+{
+    const float ax = absf(x), ay = absf(y), az = absf(z);
+    return (__builtin_elementwise_minimum(__builtin_elementwise_minimum(ax, ay), az) >= 0x1p-126f) &
+           (__builtin_elementwise_maximum(__builtin_elementwise_maximum(ax, ay), az) < 0x1p126f);
+}
+// |x|, |y|, |z| all <= FLT_MAX (false for a NaN, as the three comparisons are)
+__device__ __forceinline__ bool finite3(const float x, const float y, const float z)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(absf(x), absf(y)), absf(z)) <= FLT_MAX;
+}
 __device__ __forceinline__ float rcp_short(const float x)
 {
     const float r0 = __builtin_amdgcn_rcpf(x);
@@ -1007,7 +1025,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     F3 inv = f3(rcp_short(nr.d.x), rcp_short(nr.d.y), rcp_short(nr.d.z)); // 1 / d (Ray.cuh:14), see rcp_ieee
     {
         asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z));
-        const bool ok = rcp_short_ok(nr.d.x) & rcp_short_ok(nr.d.y) & rcp_short_ok(nr.d.z);
+        const bool ok = rcp_short_ok3(nr.d.x, nr.d.y, nr.d.z);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
             if (!ok) inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z);
         }
@@ -1015,8 +1033,8 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     uint32_t flags = nr.flags & ~RF_SKIP;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
-    const bool finite_inv = absf(inv.x) <= FLT_MAX && absf(inv.y) <= FLT_MAX && absf(inv.z) <= FLT_MAX; // a finite 1/d has a finite d
-    const bool finite = finite_inv && absf(nr.o.x) <= FLT_MAX && absf(nr.o.y) <= FLT_MAX && absf(nr.o.z) <= FLT_MAX;
+    const bool finite_inv = finite3(inv.x, inv.y, inv.z); // a finite 1/d has a finite d
+    const bool finite = finite_inv & finite3(nr.o.x, nr.o.y, nr.o.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
     // (MODE 0: a ray that is not RF_EXACT walks the 4-wide tree; finite implies finite_inv)
     const int ref = (MODE == 0 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
@@ -1352,7 +1370,7 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
         r0.x = __builtin_amdgcn_rcpf(det.x); r0.y = __builtin_amdgcn_rcpf(det.y);
         rcp = __builtin_elementwise_fma(__builtin_elementwise_fma(-det, r0, v2s(1.0f)), r0, r0);
         asm volatile("" : "+v"(rcp)); // (keeps the short form ahead of the branch instead of in an else-arm)
-        const bool ok = rcp_short_ok(det.x) & rcp_short_ok(det.y);
+        const bool ok = rcp_short_ok2(det.x, det.y);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
             if (!ok) { rcp.x = 1 / det.x; rcp.y = 1 / det.y; }
         }
