@@ -1426,7 +1426,7 @@ template <bool STATS, class LDS>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
                                             const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu)
 {
-    const float4* nd = sc.nodes4 + (size_t)ref * 8;
+    const float4* nd = (const float4*)((const char*)sc.nodes4 + (uint32_t)ref * 128u); // 32-bit byte offset: scalar base + vector offset addressing
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 uint32_t rec = (uint32_t)~ref;
                 int it0 = 0, left = 1;
                 for (int k = 0; left > 0 && !done; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
-                    const float4* lg = sc.leaf_geo + (size_t)rec * 5;
+                    const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u); // (32-bit byte offset, as for the nodes)
                     const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
                     const int it = __float_as_int(g4.z);
                     if (k == 0) { it0 = it; left = __float_as_int(g4.w); }
@@ -2247,6 +2247,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
         if (pipeline != 2) pipeline = 4;
         if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 2; // k_mega3 keeps the best triangle's offset in its leaf in 16 bits
+        if (pipeline == 4 && (sc->nodes4.n * sizeof(float4) >= (1ull << 32) || sc->leaf_geo.n * sizeof(float4) >= (1ull << 32)))
+            pipeline = 2; // k_mega3 addresses nodes and leaf records with 32-bit byte offsets (33 M nodes / 53 M records)
         if (pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
