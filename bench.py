@@ -3,37 +3,49 @@
 (BASELINE.json configs[1]) on N MI355X of one node.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+      N > 1, started plainly: this process touches no GPU; it starts N ranks of itself (RANK / LOCAL_RANK /
+      WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), one process per GPU over RCCL, and
+      relays rank 0's JSON line -- the same ranks `python -m torch.distributed.run --nproc-per-node N bench.py
+      --gpus N ...` starts (that launcher works too: the ranks find WORLD_SIZE in the environment).
+  python bench.py --gpus N --engine multi
+      ONE process, N devices: the in-library entry crt_multi_render (include/crt.h) -- a host thread and a stream
+      per device, one ncclAllGather over RCCL, no torch.distributed.
 
-A "step" is one complete frame: every rank path-traces its interleaved 8x8 pixel
-tiles with the HIP kernels of libcrt.so, the compact RGB8 tile buffers are
-all-gathered over RCCL and de-interleaved into the final image on every rank.
+A "step" is one complete frame: every rank path-traces its interleaved 8x8 pixel tiles with the HIP kernels of
+libcrt.so, the compact RGB8 tile buffers are all-gathered over RCCL and de-interleaved into the final image.
 The total work is fixed as N grows ("strong" scaling).
 
-A ray is one closest-hit query of the reference (DeviceBVH::intersect): primary,
-bounce, shadow and specular-probe rays; the count is deterministic given
-(scene, config, seed) and comes from the kernel's counters.
+A ray is one closest-hit query of the reference (DeviceBVH::intersect): primary, bounce, shadow and specular-probe
+rays; the count is deterministic given (scene, config, seed) and comes from the kernel's counters.
 
-roofline (dominant kernel: k_mega3, the persistent path-tracing megakernel, one
-launch per frame): algorithmic bytes per ray B_ray = 64 B x
-inner-node visits + 8 B x leaf visits + 36 B x triangle tests + 16 B x hits of
-the REFERENCE traversal's visit set, measured with the
-exhaustive counting kernel on a spp=8 slice of the same frame; achieved =
-(rays per launch x B_ray) / (average k_mega3 launch duration from HIP events on
-the launching stream); peak = 8 TB/s HBM3E.  The production traversal walks a
-SAH tree over the reference's leaves and prunes, so it touches far fewer nodes
-than the reference's visit set: `achieved_visited` prices the nodes it really
-visits the same way.  The scene (a few MB) is cache resident, real HBM traffic
-(`traffic`, from rocprofv3 FETCH_SIZE/WRITE_SIZE) is far below both -- see
-DESIGN.md "Roofline".
+roofline -- dominant kernel k_mega3 (persistent path-tracing megakernel, one launch per frame).  The kernel's time is
+measured live (HIP events on the launching stream); the counts it is set against come from rocprofv3 PMC passes of
+the same workload, kept in profiles/pmc_latest.json and STAMPED with a hash of the kernel sources and build flags:
+when the hash differs from the library that is running, the counter-based fields are null (never a stale number).
+Three candidate bounds are priced, each with a fraction <= 1 by construction, and the largest one is reported as
+`roofline.frac` / `roofline.bound`:
+    hbm        memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md
+               prescribes) / t against 8 TB/s;
+    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / (cycles per wave64 VALU instruction with four waves per
+               SIMD, tools/valu_issue_bench.hip);
+    l2         TCC requests x 128 B / t against the L2 peak.
+The SURVEY 8(d) contract figure -- algorithmic bytes of the REFERENCE traversal's visit set, B_ray = 64 x inner
+visits + 8 x leaf visits + 36 x triangle tests + 16 x hits, counted by the exhaustive kernel on a spp=8 slice --
+stays as `contract_*` side fields: the production traversal walks a 4-wide SAH tree over the reference's leaves and
+prunes, so it does not perform that work and the figure exceeds the HBM peak (it is not a bound).
 
-cpu_baseline: the single-threaded CPU oracle (a port of the reference algorithm,
-oracle/crt_oracle.cpp) timed on this host on the same scene at 800x600 spp=2
-(BASELINE.json configs[0]), rank 0, N=1 only.
+parity (same run): the frame the cpu_baseline leg renders on the oracle (800x600 at --cpu-spp) is
+rendered on the GPU too and compared over all pixels; the FAST traversal is also compared with the exhaustive
+REFERENCE traversal on that slice.
+
+cpu_baseline: the single-threaded CPU oracle (a port of the reference algorithm, oracle/crt_oracle.cpp) timed on
+this host on the same scene at 800x600 spp=--cpu-spp, rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,10 +53,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E (MI355X_MICROARCH.md)
+L2_PEAK_GBPS = 34500.0       # 8 XCDs x 16 channels x 128 B/clk at 2.1 GHz
+N_SIMDS = 1024               # 256 CUs x 4
+CLOCK_GHZ = 2.4
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -55,37 +71,100 @@ def main():
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--engine", default="procs", choices=["procs", "multi"],
+                    help="procs: one process per GPU, torch.distributed over RCCL; multi: one process, crt_multi_render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the veach-mis 800x600 spp=1024 sub-record")
     ap.add_argument("--cpu-spp", type=int, default=8)
     ap.add_argument("--save-png", default=None)
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` started plainly: start the N ranks as child processes BEFORE anything touches a GPU
+    (a process that has initialised HIP must never exec or fork workers) and relay their exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+                    "CRT_BENCH_SPAWNED": "1"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def load_pmc(workload_key):
+    """Counters of `workload_key` from profiles/pmc_latest.json if they were collected on the code that is running."""
+    from cudaraytracing_amd import build as B
+    try:
+        d = json.load(open(PMC_FILE))
+    except Exception:
+        return None, "profiles/pmc_latest.json missing"
+    if d.get("src_hash") != B.source_hash():
+        return None, "profiles/pmc_latest.json was collected on other kernel sources (%s, running %s): counter-based fields dropped" % (
+            d.get("src_hash"), B.source_hash())
+    w = d.get("workloads", {}).get(workload_key)
+    if not w:
+        return None, "profiles/pmc_latest.json has no workload %s" % workload_key
+    return w, None
+
+
+def bounds_from_pmc(pmc, k_s):
+    """The three candidate bounds for one launch of duration k_s seconds; every fraction is <= 1 by construction."""
+    out = {}
+    cyc = float(pmc.get("valu_cycles_per_instr", 2.0))
+    if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+        traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
+        out["hbm"] = {"achieved": round(traffic / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": traffic}
+    if pmc.get("SQ_INSTS_VALU") is not None:
+        peak = N_SIMDS * CLOCK_GHZ / cyc
+        ach = pmc["SQ_INSTS_VALU"] / k_s / 1e9
+        out["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+                             "cycles_per_instr": cyc, "lane_utilization": pmc.get("valu_lane_utilization")}
+    if pmc.get("TCC_REQ_sum") is not None or (pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None):
+        req = pmc.get("TCC_REQ_sum")
+        if req is None:
+            req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
+        ach = req * 128.0 / k_s / 1e9
+        out["l2"] = {"achieved": round(ach, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / L2_PEAK_GBPS, 4)}
+    return out
+
+
+def main_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import cudaraytracing_amd as crt
+    from cudaraytracing_amd import build as B
     from cudaraytracing_amd.distributed import render_sharded
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+    multi = args.engine == "multi"
+    rank = 0 if multi else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if multi else int(os.environ.get("LOCAL_RANK", "0"))
+    world = 1 if multi else int(os.environ.get("WORLD_SIZE", "1"))
+    if not multi and world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    # CRT_BENCH_ONE_DEVICE=1 (testing only): all ranks share cuda:0 and gather over gloo, to exercise the
-    # N > 1 code path on a single-GPU box (RCCL refuses two ranks on one device)
+    # CRT_BENCH_ONE_DEVICE=1 (testing only): all ranks share cuda:0 (procs: gather over gloo; multi: peer copies) to exercise
+    # the N > 1 code path on a single-GPU box (RCCL refuses two ranks on one device)
     one_device = os.environ.get("CRT_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_device else "nccl"
         if one_device:
             dist.init_process_group(backend="gloo")
         else:
@@ -102,11 +181,24 @@ def main():
     eye = task.eye_pos
     inv_view = crt.get_inverse_view_matrix(task.eye_pos, task.lookat, task.up)
     fov = crt.fov_to_radians(task.fov_y)
+    trav = crt.TRAVERSAL_FAST if args.traversal == "fast" else crt.TRAVERSAL_REFERENCE
+    mr = None
+    if multi:
+        devs = [0] * args.gpus if one_device else list(range(args.gpus))
+        mr = crt.MultiRender(scene, args.spp, task.P_RR, task.light_sample_n, devices=devs,
+                             gather=crt.GATHER_COPY if one_device else (crt.GATHER_RCCL if args.gpus > 1 else crt.GATHER_AUTO))
+        mr.seed = args.seed
+        mr.traversal = trav
     render = crt.Render(scene, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
     render.seed = args.seed
-    render.traversal = crt.TRAVERSAL_FAST if args.traversal == "fast" else crt.TRAVERSAL_REFERENCE
+    render.traversal = trav
 
     def step():
+        if multi:
+            mr.run_view(eye, inv_view, fov, want_mean=False, width=args.width, height=args.height, to_host=False)
+            st = dict(mr.stats)
+            st["kernel_ms"] = mr.info["max_kernel_ms"]
+            return None, st
         return render_sharded(render, eye, inv_view, fov, args.width, args.height, rank, world, device)
 
     for _ in range(args.warmup):
@@ -136,41 +228,70 @@ def main():
     rays_frame = float(r.item())
     ms_per_step = elapsed * 1e3 / args.steps
     mrays = rays_frame * args.steps / elapsed / 1e6
+    n_gpus = args.gpus
+    single = n_gpus == 1
 
     if rank == 0:
-        # ---- roofline: bytes per ray from the counting kernels on a spp=8 slice of the same frame ----
+        c2 = args.scene == "cornell-box" and (args.width, args.height, args.spp) == (800, 600, 512)
+        # ---- contract figure: bytes per ray from the counting kernels on a spp=8 slice of the same frame; the same two renders
+        #      give the FAST == REFERENCE cross-check (every pixel of the slice, float bits) ----
         def visit_bytes(st, node_bytes=64.0):
             return (node_bytes * st["inner_pops"] + 8.0 * st["leaf_pops"] + 36.0 * st["tri_tests"] + 16.0 * st["hits"]) / st["rays"]
 
         render.set_spp(8)
         render.traversal = crt.TRAVERSAL_REFERENCE
-        render.run_view(eye, inv_view, fov, stats=True, want_mean=False, width=args.width, height=args.height)
+        render.run_view(eye, inv_view, fov, stats=True, want_mean=True, width=args.width, height=args.height)
+        ref_mean, ref_rgb, ref_rays = render.mean_buffer.copy(), render.frame_buffer.copy(), render.stats["rays"]
         b_ray = visit_bytes(render.stats)
         ref_visits = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
         render.traversal = crt.TRAVERSAL_FAST
-        render.run_view(eye, inv_view, fov, stats=True, want_mean=False, width=args.width, height=args.height)
+        render.run_view(eye, inv_view, fov, stats=True, want_mean=True, width=args.width, height=args.height)
         b_ray_visited = visit_bytes(render.stats, 112.0)  # the FAST traversal walks the 4-wide tree: 4 boxes + 4 refs per node
+        fast_visits = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
+        fast_vs_reference = {
+            "sample": "%s %dx%d spp=8, all pixels" % (args.scene, args.width, args.height),
+            "pixels_differ_f32_bits": int(np.count_nonzero(np.any(render.mean_buffer.view(np.uint32) != ref_mean.view(np.uint32), axis=2))),
+            "rgb8_mismatch": int(np.count_nonzero(np.any(render.frame_buffer != ref_rgb, axis=2))),
+            "rays_equal": bool(render.stats["rays"] == ref_rays)}
         launches = max(1, int(np.mean(kernel_launches)))
-        k_ms_total = float(np.mean(kernel_ms))           # sum of the kernel's launch durations of one frame (rank 0)
+        k_ms_total = float(np.mean(kernel_ms))           # sum of the kernel's launch durations of one frame (rank 0 / slowest rank)
         k_ms = k_ms_total / launches                     # average launch duration
         rays_launch = float(rays_local) / launches
-        achieved = rays_launch * b_ray / (k_ms * 1e-3) / 1e9
-        achieved_visited = rays_launch * b_ray_visited / (k_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        contract = rays_launch * b_ray / (k_ms * 1e-3) / 1e9
+        contract_visited = rays_launch * b_ray_visited / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                     "kernel": "k_mega3", "launches_per_frame": launches, "avg_launch_ms": round(k_ms, 4),
-                    "kernel_ms_per_frame": round(k_ms_total, 3), "logic_kernel_ms_per_frame": round(float(np.mean(logic_ms)), 3),
-                    "rays_per_launch": int(rays_launch), "bytes_per_ray": round(b_ray, 1),
-                    "reference_visits_per_ray": ref_visits,
-                    "achieved_visited": round(achieved_visited, 2), "bytes_per_ray_visited": round(b_ray_visited, 1),
-                    "frac_visited": round(achieved_visited / HBM_PEAK_GBPS, 4),
-                    "note": "achieved prices the reference's exhaustive visit set (SURVEY 8(d)); the kernel prunes and "
-                            "walks a SAH tree over the same leaves, so frac can exceed 1; the scene is cache resident and the "
-                            "kernel is bound by instruction issue / divergent 16 B loads, not by HBM (DESIGN.md)"}
+                    "kernel_ms_per_frame": round(k_ms_total, 3), "rays_per_launch": int(rays_launch),
+                    "compulsory_bytes_per_launch": int(16 * args.width * args.height * args.spp / max(1, launches) / n_gpus),
+                    "contract_bytes_per_ray": round(b_ray, 1), "contract_achieved": round(contract, 2),
+                    "contract_frac": round(contract / HBM_PEAK_GBPS, 4), "contract_unit": "GB/s",
+                    "contract_note": "SURVEY 8(d): algorithmic bytes of the REFERENCE traversal's visit set / kernel time; the kernel "
+                                     "does not perform that work (4-wide SAH tree over the same leaves, pruning, any-hit), so this is not a bound",
+                    "reference_visits_per_ray": ref_visits, "fast_visits_per_ray": fast_visits,
+                    "visited_bytes_per_ray": round(b_ray_visited, 1), "visited_achieved": round(contract_visited, 2)}
+        pmc, pmc_note = (load_pmc("c2") if (c2 and single) else (None, "PMC passes exist for the C2 workload on one GPU only"))
+        if pmc is not None:
+            bounds = bounds_from_pmc(pmc, k_ms * 1e-3)
+            roofline["bounds"] = bounds
+            if bounds:
+                name = max(bounds, key=lambda b: bounds[b]["frac"])
+                roofline.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
+                                 "unit": bounds[name]["unit"], "frac": bounds[name]["frac"]})
+            if "hbm" in bounds:
+                roofline["traffic"] = bounds["hbm"]["bytes_per_launch"]
+            roofline["pmc"] = {"src_hash": B.source_hash(), "collected": pmc.get("collected"), "profiled_launch_ms": pmc.get("avg_launch_ms"),
+                               "salu_per_valu": pmc.get("salu_per_valu"), "wait_any_frac": pmc.get("SQ_WAIT_ANY/WAVE_CYCLES"),
+                               "tcc_miss_frac": pmc.get("tcc_miss_frac")}
+            roofline["note"] = ("counts from rocprofv3 --pmc passes of this exact workload and code (hash-stamped), time from HIP events of this "
+                                "run; the largest of the three fractions names the bound; the scene is cache resident and the kernel is "
+                                "latency bound (SQ_WAIT_ANY), see DESIGN.md")
+        else:
+            roofline["note"] = pmc_note
+
         # ---- the same frame with every next-event sample traced (CRT_FLAG_TRACE_ALL): the default path answers the samples whose
         #      contribution is exactly zero without traversal (same frame bit for bit; they still count as rays of the reference) ----
         all_traced = None
-        if world == 1:
+        if single and not multi:
             render.set_spp(args.spp)
             render.extra_flags = crt.FLAG_TRACE_ALL
             step()
@@ -182,31 +303,90 @@ def main():
             render.extra_flags = 0
             all_traced = {"ms_per_step": round(dt_all * 1e3, 3), "mrays_per_sec": round(st_all["rays"] / dt_all / 1e6, 2),
                           "kernel_ms": round(st_all["kernel_ms"], 3)}
-        traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
-        c2 = args.scene == "cornell-box" and (args.width, args.height, args.spp) == (800, 600, 512) and world == 1
-        if c2 and os.path.exists(traffic_file):  # the PMC passes were collected on this exact workload
-            try:
-                roofline["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
-            except Exception:
-                pass
 
+        # ---- C3 (veach-mis 800x600 spp=1024: divergence stress) timed by the same run ----
+        c3 = None
+        if single and c2 and not multi and not args.no_c3:
+            t3 = crt.Task(os.path.join(ROOT, "scenes", "veach-mis", "config.json"), base_dir=ROOT)
+            s3 = crt.Scene.from_task(t3, 800, 600)
+            r3 = crt.Render(s3, 1024, t3.P_RR, t3.light_sample_n, device=local_rank)
+            r3.seed = args.seed
+            iv3 = crt.get_inverse_view_matrix(t3.eye_pos, t3.lookat, t3.up)
+            f3 = crt.fov_to_radians(t3.fov_y)
+
+            def step3():
+                return render_sharded(r3, t3.eye_pos, iv3, f3, 800, 600, 0, 1, device)
+
+            step3()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            k3 = []
+            for _ in range(3):
+                _, st3 = step3()
+                k3.append(st3["kernel_ms"])
+            torch.cuda.synchronize(device)
+            dt3 = (time.perf_counter() - c0) / 3
+            r3.extra_flags = crt.FLAG_TRACE_ALL
+            step3()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            _, st3a = step3()
+            torch.cuda.synchronize(device)
+            dt3a = time.perf_counter() - c0
+            r3.extra_flags = 0
+            c3 = {"workload": "veach-mis 800x600 spp=1024 P_RR=%g light_sample_n=%d" % (float(t3.P_RR), t3.light_sample_n), "frames": 3,
+                  "ms_per_frame": round(dt3 * 1e3, 3), "kernel_ms": round(float(np.mean(k3)), 3), "rays_per_frame": int(st3["rays"]),
+                  "mrays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
+                  "mrays_traced_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),
+                  "untraced_frac": round(st3["rays_untraced"] / st3["rays"], 4),
+                  "all_rays_traced_ms": round(dt3a * 1e3, 3)}
+            p3, _ = load_pmc("c3")
+            if p3 is not None:
+                c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3)
+            r3.free()
+
+        # ---- CPU baseline + same-run parity gate: the oracle renders the 800x600 spp=--cpu-spp frame on one host
+        #      thread; the GPU renders the same frame; every pixel is compared ----
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        parity = None
+        if single and not args.no_cpu_baseline:
             import oracle_lib as O
             osc = O.OracleScene(task.OBJ_paths, task.bvh_thresh_n)
             c0 = time.perf_counter()
-            _, _, _, ost = osc.render(eye, inv_view, fov, args.width, args.height, args.cpu_spp, task.P_RR,
-                                      task.light_sample_n, seed=args.seed)
+            orgb, omean, _, ost = osc.render(eye, inv_view, fov, args.width, args.height, args.cpu_spp, task.P_RR,
+                                             task.light_sample_n, seed=args.seed)
             cdt = time.perf_counter() - c0
             cpu = {"value": round(ost["rays"] / cdt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                    "sample": "%s %dx%d spp=%d (%d paths, %d rays) in %.1f s, single thread"
                              % (args.scene, args.width, args.height, args.cpu_spp, ost["paths"], ost["rays"], cdt),
                    "ms_per_frame_extrapolated": round(cdt * 1e3 * args.spp / args.cpu_spp, 1)}
-        if args.save_png:
+            render.set_spp(args.cpu_spp)
+            render.traversal = trav
+            render.run_view(eye, inv_view, fov, stats=False, want_mean=True, width=args.width, height=args.height)
+            gm, gr = render.mean_buffer, render.frame_buffer
+            diff = np.abs(gm.astype(np.float64) - omean.astype(np.float64))
+            both_nan = np.isnan(gm) & np.isnan(omean)
+            diff[both_nan] = 0.0
+            diff[np.isnan(diff)] = np.inf
+            parity = {"sample": "%s %dx%d spp=%d, all %d pixels, GPU (%s traversal) vs single-thread CPU oracle"
+                                % (args.scene, args.width, args.height, args.cpu_spp, args.width * args.height, args.traversal),
+                      "tolerance": 1e-5,
+                      "pixels_gt_1e-5": int(np.count_nonzero(np.any(diff > 1e-5, axis=2))),
+                      "max_abs": float(diff.max()),
+                      "pixels_differ_f32_bits": int(np.count_nonzero(np.any((gm.view(np.uint32) != omean.view(np.uint32)) & ~both_nan, axis=2))),
+                      "rgb8_mismatch": int(np.count_nonzero(np.any(gr != orgb, axis=2))),
+                      "rays_equal": bool(render.stats["rays"] == ost["rays"]),
+                      "rays": int(ost["rays"])}
+        if args.save_png and img is not None:
             from PIL import Image
             Image.fromarray(img.cpu().numpy()).save(args.save_png)
+        rccl_ranks = 0
+        if multi:
+            rccl_ranks = int(mr.info["rccl_ranks"])
+        elif world > 1 and backend == "nccl":
+            rccl_ranks = dist.get_world_size()
         line = {
-            "metric": "Mrays/sec", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "metric": "Mrays/sec", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d spp=%d P_RR=%g light_sample_n=%d (stand-in cornell-box.obj, 40972 triangles)"
@@ -214,28 +394,52 @@ def main():
                        if args.scene == "cornell-box" else
                        "%s %dx%d spp=%d P_RR=%g light_sample_n=%d" % (args.scene, args.width, args.height, args.spp,
                                                                       float(task.P_RR), task.light_sample_n),
-                       "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % world, "seed": args.seed,
+                       "traversal": args.traversal, "parallelism": "pixel-tiles x%d" % n_gpus, "seed": args.seed,
+                       "engine": "one process, crt_multi_render" if multi else "one process per GPU, torch.distributed",
                        "untraced_samples": "next-event samples whose contribution is exactly zero are answered without traversal "
-                                           "(frame bit-identical, still counted as rays of the reference): %.1f%% of the rays on rank 0; "
+                                           "(frame bit-identical, still counted as rays of the reference): %.1f%% of the rays%s; "
                                            "`all_rays_traced` times the same frame with every one of them traced"
-                                           % (100.0 * untraced_local / max(1, rays_local))},
+                                           % (100.0 * untraced_local / max(1, rays_local), "" if multi else " on rank 0")},
             "frames_per_sec": round(1e3 / ms_per_step, 4),
             "rays_per_frame": int(rays_frame),
             "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
                                "equal to the oracle's count",
+            "collective": {"backend": ("rccl" if rccl_ranks else ("copy" if multi and n_gpus > 1 else (backend or "none"))),
+                           "rccl_ranks": rccl_ranks,
+                           "launched_by": "torch.distributed.run" if (world > 1 and not os.environ.get("CRT_BENCH_SPAWNED")) else
+                                          ("bench.py (self-started ranks)" if world > 1 else "single process")},
+            "build_flags": B.built_flags(),
             "rays_untraced_per_frame_rank0": int(untraced_local),
-            "mrays_traced_per_sec": round((rays_frame - (untraced_local if world == 1 else 0)) * args.steps / elapsed / 1e6, 2) if world == 1 else None,
+            "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
             "all_rays_traced": all_traced,
             "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
             "roofline": roofline,
+            "fast_vs_reference": fast_vs_reference,
         }
+        if multi:
+            line["multi_info"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in mr.info.items()}
+        if parity is not None:
+            line["parity"] = parity
+        if c3 is not None:
+            line["c3"] = c3
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     render.free()
+    if mr is not None:
+        mr.free()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if args.engine == "procs" and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    main_rank(args)
 
 
 if __name__ == "__main__":

@@ -14,6 +14,7 @@ FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4
 FLAG_TRACE_ALL = 8
+GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
 TILE = 8
 
 
@@ -73,6 +74,15 @@ class Stats(C.Structure):
         return d
 
 
+class MultiInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("gather", C.c_uint32), ("rccl_ranks", C.c_uint32), ("rccl_version", C.c_int32),
+                ("render_ms", C.c_float), ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("max_kernel_ms", C.c_float),
+                ("bytes_per_rank", C.c_uint64), ("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_untraced", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class Task(C.Structure):
     _fields_ = [("n_objs", C.c_uint32), ("obj_path", (C.c_char * 512) * 8), ("mtl_dir", (C.c_char * 512) * 8),
                 ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("eye_pos", C.c_float * 3), ("fov_y", C.c_float),
@@ -88,7 +98,8 @@ LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
-           "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_intersect",
+           "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_multi_create", "crt_multi_destroy",
+           "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_desc", "crt_host_scene_num_objects",
            "crt_host_scene_object", "crt_inverse_view", "crt_task_load", "crt_write_png"]
@@ -121,6 +132,11 @@ def lib():
                                    C.POINTER(Stats)]
     L.crt_render_range_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.crt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.crt_multi_destroy.argtypes = [C.c_void_p]
+    L.crt_multi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats),
+                                   C.POINTER(MultiInfo)]
+    L.crt_multi_frame_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     L.crt_intersect.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     L.crt_device_math.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crt_device_philox.argtypes = [C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -261,6 +261,69 @@ class Render:
             pass
 
 
+class MultiRender(Render):
+    """Render over several devices of one node in ONE process (include/crt.h, crt_multi): one replica of the scene per entry
+    of `devices`, interleaved pixel-tile shards, one RCCL all-gather per frame.  The reference stops at device 0
+    (src/main.cu:92-105)."""
+
+    def __init__(self, scene, spp=16, P_RR=0.8, light_sample_n=1, devices=(0,), gather=capi.GATHER_AUTO):
+        self.scene = scene
+        self.spp, self.P_RR, self.light_sample_n = int(spp), np.float32(P_RR), int(light_sample_n)
+        self.seed = 0
+        self.traversal = capi.TRAVERSAL_FAST
+        self.extra_flags = 0
+        self.devices = [int(d) for d in devices]
+        self.device = self.devices[0]
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        capi.check(capi.lib().crt_multi_create(C.byref(scene.desc()), devs, len(self.devices), gather, C.byref(self._h)),
+                   "crt_multi_create")
+        self.frame_buffer = None
+        self.mean_buffer = None
+        self.stats = None
+        self.rank_stats = None
+        self.info = None
+
+    def run_view(self, eye_pos, inv_view_mat, fovY, stats=False, want_mean=True, width=None, height=None, to_host=True):
+        if not self._h:
+            raise RuntimeError("MultiRender.run_view after free()")
+        cam = self._cam(eye_pos, inv_view_mat, fovY)
+        prm = self._params(flags=(capi.FLAG_STATS if stats else 0) | self.extra_flags, width=width, height=height)
+        w, h = prm.width, prm.height
+        rgb = np.zeros((h, w, 3), dtype=np.uint8) if to_host else None
+        mean = np.zeros((h, w, 3), dtype=np.float32) if (want_mean and to_host) else None
+        st = (capi.Stats * len(self.devices))()
+        info = capi.MultiInfo()
+        capi.check(capi.lib().crt_multi_render(self._h, C.byref(cam), C.byref(prm), capi.ptr(rgb), capi.ptr(mean), st,
+                                               C.byref(info)), "crt_multi_render")
+        self.rank_stats = [s.as_dict() for s in st]
+        self.info = info.as_dict()
+        tot = dict(self.rank_stats[0])
+        for o in self.rank_stats[1:]:
+            for k in ("paths", "rays", "shadow_rays", "probe_rays", "rays_untraced", "inner_pops", "leaf_pops", "tri_tests", "hits"):
+                tot[k] += o[k]
+            for k in ("kernel_ms", "total_ms"):
+                tot[k] = max(tot[k], o[k])
+        self.stats = tot
+        if to_host:
+            self.frame_buffer, self.mean_buffer = rgb, mean
+        return rgb
+
+    def run_view_range(self, *a, **k):
+        raise NotImplementedError("progressive ranges are a single-device interface (crt_render_range)")
+
+    def run_view_device(self, *a, **k):
+        raise NotImplementedError("MultiRender owns its device buffers (crt_multi_frame_device)")
+
+    def intersect(self, *a, **k):
+        raise NotImplementedError("crt_intersect is a single-device interface")
+
+    def free(self):
+        if self._h:
+            capi.lib().crt_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+
 def shard_slots(width, height, rank, world):
     n = C.c_uint64()
     capi.check(capi.lib().crt_shard_slots(width, height, rank, world, C.byref(n)), "crt_shard_slots")

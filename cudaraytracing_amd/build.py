@@ -20,12 +20,41 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"] + os.environ.get("CRT_EXTRA_CXXFLAGS", "").split()
 DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
-LIB_SOURCES = ["crt_kernels.hip", "crt_host.cpp"]
-LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", os.path.join("..", "..", "include", "crt.h")]
+LIB_SOURCES = ["crt_kernels.hip", "crt_multi.hip", "crt_host.cpp"]
+LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", "crt_png.h",
+                          os.path.join("..", "..", "include", "crt.h")]
+FLAGS_FILE = os.path.join(LIBDIR, "libcrt.flags")  # the flag string libcrt.so was built with (a variant build is stale for a default run)
 
 
-def _stale(target, deps):
+def flags_string():
+    return " ".join(COMMON + DEVICE)
+
+
+def built_flags():
+    """Flag string of the libcrt.so in the tree ("" if unknown)."""
+    try:
+        with open(FLAGS_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
+def source_hash():
+    """SHA-256 over the sources libcrt.so is built from and the flag string: stamps profiles (bench.py drops PMC numbers
+    collected on other code)."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(LIB_DEPS):
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    h.update(flags_string().encode())
+    return h.hexdigest()[:16]
+
+
+def _stale(target, deps, check_flags=False):
     if not os.path.exists(target):
+        return True
+    if check_flags and built_flags() != flags_string():
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
@@ -33,12 +62,14 @@ def _stale(target, deps):
 
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not _stale(LIB, LIB_DEPS):
+    if not force and not _stale(LIB, LIB_DEPS, check_flags=True):
         return LIB
-    cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-ldl", "-lpthread", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(flags_string() + "\n")
     return LIB
 
 

@@ -6,6 +6,9 @@
 //
 //   crt_cli <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]
 //           [--eye x y z] [--lookat x y z] [--up x y z] [--reference] [--base-dir DIR] [--device N]
+//           [--gpus N | --devices a,b,...] [--gather auto|rccl|copy]
+// --gpus N renders on devices 0..N-1 of this node in one process (crt_multi: interleaved pixel tiles, one RCCL all-gather);
+// --devices names the device of every rank explicitly (a repeated index puts two ranks on one GPU: --gather copy only).
 #include "crt_host.hpp"
 
 #include <chrono>
@@ -14,12 +17,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 int main(int argc, char** argv)
 {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]\n"
-                             "       [--eye x y z] [--lookat x y z] [--up x y z] [--reference] [--base-dir DIR] [--device N]\n", argv[0]);
+                             "       [--eye x y z] [--lookat x y z] [--up x y z] [--reference] [--base-dir DIR] [--device N]\n"
+                             "       [--gpus N | --devices a,b,...] [--gather auto|rccl|copy]\n", argv[0]);
         return 2;
     }
     try {
@@ -28,6 +33,8 @@ int main(int argc, char** argv)
         uint64_t seed = 0;
         int device = 0;
         bool reference = false;
+        std::vector<int> devices;
+        uint32_t gather = CRT_GATHER_AUTO;
         auto need = [&](int i, int n) { if (i + n >= argc) throw crt::Error(CRT_ERR_INVALID_ARG, std::string("missing value after ") + argv[i]); };
         for (int i = 2; i < argc; i++) {
             std::string a = argv[i];
@@ -39,6 +46,28 @@ int main(int argc, char** argv)
             else if (a == "--width") { need(i, 1); task.width = (uint32_t)std::atoi(argv[++i]); }
             else if (a == "--height") { need(i, 1); task.height = (uint32_t)std::atoi(argv[++i]); }
             else if (a == "--device") { need(i, 1); device = std::atoi(argv[++i]); }
+            else if (a == "--gpus") {
+                need(i, 1);
+                const int n = std::atoi(argv[++i]);
+                if (n < 1) throw crt::Error(CRT_ERR_INVALID_ARG, "--gpus needs a positive count");
+                devices.clear();
+                for (int k = 0; k < n; k++) devices.push_back(k);
+            } else if (a == "--devices") {
+                need(i, 1);
+                devices.clear();
+                for (const char* q = argv[++i]; *q;) {
+                    char* end = nullptr;
+                    const long v = std::strtol(q, &end, 10);
+                    if (end == q) throw crt::Error(CRT_ERR_INVALID_ARG, "--devices needs a comma-separated list of device indices");
+                    devices.push_back((int)v);
+                    q = *end == ',' ? end + 1 : end;
+                }
+            } else if (a == "--gather") {
+                need(i, 1);
+                const std::string g = argv[++i];
+                if (g == "auto") gather = CRT_GATHER_AUTO; else if (g == "rccl") gather = CRT_GATHER_RCCL; else if (g == "copy") gather = CRT_GATHER_COPY;
+                else throw crt::Error(CRT_ERR_INVALID_ARG, "--gather must be auto, rccl or copy");
+            }
             else if (a == "--base-dir") { need(i, 1); base_dir = argv[++i]; }
             else if (a == "--reference") reference = true;
             else if (a == "--eye" || a == "--lookat" || a == "--up") {
@@ -52,7 +81,10 @@ int main(int argc, char** argv)
         scene.set_BVH(task.bvh_thresh_n);
         std::printf("triangles: %zu, BVH nodes: %zu, lights: %zu\n", scene.get_triangles().size(), scene.get_bvh().get_nodes_size(),
                     scene.get_light_objs().size());
-        crt::Render render(&scene, task.spp, task.p_rr, task.light_sample_n, device);
+        const bool multi = !devices.empty();
+        crt::Render render_one_or_many = multi ? crt::Render(&scene, task.spp, task.p_rr, task.light_sample_n, devices, gather)
+                                               : crt::Render(&scene, task.spp, task.p_rr, task.light_sample_n, device);
+        crt::Render& render = render_one_or_many;
         render.set_seed(seed);
         render.set_traversal(reference ? CRT_TRAVERSAL_REFERENCE : CRT_TRAVERSAL_FAST);
         float inv_view[9];
@@ -64,6 +96,12 @@ int main(int argc, char** argv)
         const crt_stats& st = render.last_stats();
         std::printf("render cost: %.6f seconds (device %.3f ms, %llu rays, %.1f Mrays/s)\n", dt.count(), st.total_ms,
                     (unsigned long long)st.rays, st.total_ms > 0 ? st.rays / st.total_ms / 1e3 : 0.0);
+        if (multi) {
+            const crt_multi_info& mi = render.last_multi_info();
+            std::printf("ranks: %u, gather: %s, rccl ranks: %u (rccl %d), %llu B per rank, render %.3f ms + gather %.3f ms\n", mi.n_ranks,
+                        mi.gather == CRT_GATHER_RCCL ? "rccl" : "copy", mi.rccl_ranks, mi.rccl_version, (unsigned long long)mi.bytes_per_rank,
+                        mi.render_ms, mi.gather_ms);
+        }
         render.save_frame_buffer(out.c_str());
         std::printf("%s\n", out.c_str());
         render.free();

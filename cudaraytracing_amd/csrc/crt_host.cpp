@@ -530,11 +530,26 @@ Render::Render(Scene* scene, unsigned spp, float P_RR, unsigned light_sample_n, 
     frame_buffer_.assign((size_t)3 * scene->get_pixels(), 0);
     mean_buffer_.assign((size_t)3 * scene->get_pixels(), 0.0f);
 }
+// Several devices (the reference stops at device 0, src/main.cu:92-105): one replica of the scene per entry of `devices`, the
+// frame sharded by interleaved pixel tiles and gathered with one RCCL all-gather (include/crt.h, crt_multi).
+Render::Render(Scene* scene, unsigned spp, float P_RR, unsigned light_sample_n, const std::vector<int>& devices, uint32_t gather)
+    : scene_(scene), spp_(spp), light_sample_n_(light_sample_n), P_RR_(P_RR)
+{
+    if (!scene) throw Error(CRT_ERR_INVALID_ARG, "Render: null scene");
+    if (devices.empty()) throw Error(CRT_ERR_INVALID_ARG, "Render: empty device list");
+    const crt_scene_desc& d = scene->flat();
+    int rc = crt_multi_create(&d, devices.data(), (uint32_t)devices.size(), gather, &multi_);
+    if (rc != CRT_OK) throw Error(rc, std::string("Render: crt_multi_create failed: ") + crt_last_error());
+    rank_stats_.resize(devices.size());
+    frame_buffer_.assign((size_t)3 * scene->get_pixels(), 0);
+    mean_buffer_.assign((size_t)3 * scene->get_pixels(), 0.0f);
+}
 Render::~Render() { free(); }
 
 void Render::free()
 {
     if (device_scene_) { crt_scene_destroy(device_scene_); device_scene_ = nullptr; }
+    if (multi_) { crt_multi_destroy(multi_); multi_ = nullptr; }
 }
 void Render::set_width(const unsigned& w)
 {
@@ -551,7 +566,7 @@ void Render::set_height(const unsigned& h)
 
 void Render::run_view(const float eye_pos[3], const float inv_view_mat[9], float fovY)
 {
-    if (!device_scene_) throw Error(CRT_ERR_INVALID_ARG, "Render::run_view after free()");
+    if (!device_scene_ && !multi_) throw Error(CRT_ERR_INVALID_ARG, "Render::run_view after free()");
     crt_camera cam;
     std::memcpy(cam.eye, eye_pos, sizeof(cam.eye));
     std::memcpy(cam.inv_view, inv_view_mat, sizeof(cam.inv_view));
@@ -561,7 +576,21 @@ void Render::run_view(const float eye_pos[3], const float inv_view_mat[9], float
     p.width = scene_->get_width(); p.height = scene_->get_height();
     p.spp = spp_; p.p_rr = P_RR_; p.light_sample_n = (int32_t)light_sample_n_;
     p.seed = seed_; p.rank = 0; p.world = 1; p.traversal = traversal_; p.flags = 0;
-    int rc = crt_render(device_scene_, &cam, &p, frame_buffer_.data(), mean_buffer_.data(), &stats_);
+    int rc;
+    if (multi_) {
+        rc = crt_multi_render(multi_, &cam, &p, frame_buffer_.data(), mean_buffer_.data(), rank_stats_.data(), &multi_info_);
+        if (rc == CRT_OK) { // totals over the ranks; times of the slowest one
+            stats_ = rank_stats_[0];
+            for (size_t r = 1; r < rank_stats_.size(); r++) {
+                const crt_stats& o = rank_stats_[r];
+                stats_.paths += o.paths; stats_.rays += o.rays; stats_.shadow_rays += o.shadow_rays; stats_.probe_rays += o.probe_rays;
+                stats_.rays_untraced += o.rays_untraced;
+                stats_.kernel_ms = std::max(stats_.kernel_ms, o.kernel_ms); stats_.total_ms = std::max(stats_.total_ms, o.total_ms);
+            }
+        }
+    } else {
+        rc = crt_render(device_scene_, &cam, &p, frame_buffer_.data(), mean_buffer_.data(), &stats_);
+    }
     if (rc != CRT_OK) throw Error(rc, std::string("Render::run_view failed: ") + crt_last_error());
 }
 

@@ -201,6 +201,8 @@ void load_task_scene(const crt_task& task, Scene& scene, const std::string& base
 class Render {
 public:
     Render(Scene* scene, unsigned spp = 16, float P_RR = 0.8f, unsigned light_sample_n = 1, int device = 0);
+    // one rank per entry of `devices` (crt_multi: tile shards, one RCCL all-gather); gather = CRT_GATHER_*
+    Render(Scene* scene, unsigned spp, float P_RR, unsigned light_sample_n, const std::vector<int>& devices, uint32_t gather = CRT_GATHER_AUTO);
     ~Render();
     Render(const Render&) = delete;
     Render& operator=(const Render&) = delete;
@@ -218,6 +220,9 @@ public:
     void set_width(const unsigned& w);
     void set_height(const unsigned& h);
     const crt_stats& last_stats() const { return stats_; }
+    // multi-device renders: what the exchange ran on (n_ranks == 0 for a single-device Render) and the ranks' own statistics
+    const crt_multi_info& last_multi_info() const { return multi_info_; }
+    const std::vector<crt_stats>& last_rank_stats() const { return rank_stats_; }
 
 private:
     Scene* scene_;
@@ -226,6 +231,9 @@ private:
     uint64_t seed_ = 0;
     uint32_t traversal_ = CRT_TRAVERSAL_FAST;
     crt_scene* device_scene_ = nullptr;
+    crt_multi* multi_ = nullptr;
+    crt_multi_info multi_info_{};
+    std::vector<crt_stats> rank_stats_;
     std::vector<unsigned char> frame_buffer_;
     std::vector<float> mean_buffer_;
     crt_stats stats_{};

@@ -188,6 +188,44 @@ int crt_render_range(crt_scene* scene, const crt_camera* cam, const crt_params* 
 int crt_render_range_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, uint32_t sample_begin,
                             uint32_t sample_count, void* d_rgb, void* d_mean, void* hip_stream, crt_stats* stats);
 
+/* ------------------------------------------------------------------------
+ * Multi-device rendering in ONE process.  The reference picks device 0 and stops there
+ * (config_CUDA, src/main.cu:92-105); a crt_multi holds one device replica of the scene per entry of
+ * `devices` (= rank), renders the interleaved 8x8-tile shards concurrently (one host thread and one HIP
+ * stream per device), exchanges the compact tile buffers with ONE ncclAllGather over RCCL / xGMI and
+ * de-interleaves them into the row-major frame on rank 0 -- the frame is identical to crt_render's on
+ * one device, whatever the number of ranks.
+ * ---------------------------------------------------------------------- */
+typedef struct crt_multi crt_multi;
+enum {
+    CRT_GATHER_AUTO = 0,  /* RCCL when there are two or more DISTINCT devices, peer copies otherwise */
+    CRT_GATHER_RCCL = 1,  /* ncclCommInitAll + one ncclAllGather per frame (librccl.so.1 is bound at run time; its absence is CRT_ERR_UNSUPPORTED) */
+    CRT_GATHER_COPY = 2   /* every rank copies its block into rank 0's buffer (hipMemcpyPeerAsync); also the only mode that accepts
+                             several ranks on ONE device (test configuration: RCCL refuses duplicate devices) */
+};
+typedef struct {
+    uint32_t n_ranks;        /* device replicas that rendered */
+    uint32_t gather;         /* CRT_GATHER_* that ran */
+    uint32_t rccl_ranks;     /* ncclCommCount of the communicator the gather ran on; 0 with CRT_GATHER_COPY */
+    int32_t rccl_version;    /* ncclGetVersion; 0 if RCCL was not used */
+    float render_ms;         /* host clock: until the slowest rank's shard is complete */
+    float gather_ms;         /* host clock: exchange + de-interleave + copy to the host */
+    float frame_ms;          /* host clock: the whole call */
+    float max_kernel_ms;     /* largest crt_stats.kernel_ms over the ranks */
+    uint64_t bytes_per_rank; /* size of one rank's block in the exchange */
+    uint64_t rays, paths, rays_untraced; /* sums over the ranks */
+} crt_multi_info;
+/* gather: CRT_GATHER_*.  Uploads the scene to every device (crt_scene_create per rank). */
+int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_devices, uint32_t gather, crt_multi** out);
+int crt_multi_destroy(crt_multi* multi);
+/* = Render::run_view over all ranks.  params->rank / world are ignored (rank r renders tiles t % n == r).  out_rgb: W*H*3 bytes,
+ * row-major, row 0 = image top, may be NULL (the frame then stays on rank 0's device, crt_multi_frame_device); out_mean optional
+ * (needs out_rgb); stats: NULL or n_devices entries, one per rank; info optional. */
+int crt_multi_render(crt_multi* multi, const crt_camera* cam, const crt_params* params, uint8_t* out_rgb, float* out_mean,
+                     crt_stats* stats, crt_multi_info* info);
+/* device pointers of the last frame on rank 0's device (d_mean: NULL unless the last call asked for the mean) */
+int crt_multi_frame_device(crt_multi* multi, void** d_rgb, void** d_mean, int* device);
+
 /* Closest-hit query for n rays (device-side DeviceBVH::intersect,
  * DeviceBVH.cuh:128-170), host buffers. dirs are normalised as Ray's
  * constructor does (Ray.cuh:12-15). out_tri: BVH-order triangle index or -1. */

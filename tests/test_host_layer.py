@@ -149,3 +149,37 @@ def test_cornell_generator_reproduces_committed_obj(tmp_path):
     a = hashlib.sha256(open(out, "rb").read()).hexdigest()
     b = hashlib.sha256(open(os.path.join(util.ROOT, "scenes", "cornell-box", "cornell-box.obj"), "rb").read()).hexdigest()
     assert a == b
+
+
+def test_multi_device_entry_validates_arguments_without_a_gpu():
+    lib = capi.lib()
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 1)
+    assert lib.crt_multi_create(None, devs, 2, 0, C.byref(h)) == -1
+    sc = util.host_scene("veach-mis")
+    assert lib.crt_multi_create(C.byref(sc.desc()), devs, 0, 0, C.byref(h)) == -1
+    assert lib.crt_multi_create(C.byref(sc.desc()), devs, 2, 7, C.byref(h)) == -1
+    assert b"gather" in lib.crt_last_error()
+    rc = lib.crt_multi_create(C.byref(sc.desc()), devs, 2, 0, C.byref(h))
+    if rc == 0:  # (a box with two GPUs)
+        lib.crt_multi_destroy(h)
+    else:
+        assert rc in (-1, -2, -4)  # no device here / fewer than two devices / RCCL not loadable
+    assert lib.crt_multi_render(None, None, None, None, None, None, None) == -1
+    assert lib.crt_multi_destroy(None) == 0
+
+
+def test_bench_started_plainly_with_several_gpus_starts_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torch.distributed.run must start the two ranks itself (it used to exit).
+    There is no GPU here, so each rank stops at its own "needs a GPU" check -- after the launcher-free start has happened."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=util.ROOT)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by tests/test_multi_gpu.py")
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2, r.stderr[-2000:]
+    assert "must be launched with" not in r.stderr
