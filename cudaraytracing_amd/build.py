@@ -39,12 +39,15 @@ def built_flags():
         return ""
 
 
+KERNEL_DEPS = ["crt_kernels.hip", "crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h"]  # what the render kernels are made of
+
+
 def source_hash():
-    """SHA-256 over the sources libcrt.so is built from and the flag string: stamps profiles (bench.py drops PMC numbers
-    collected on other code)."""
+    """SHA-256 over the sources of the render kernels (and of the host code that lays out what they walk) and the flag
+    string: stamps profiles (bench.py drops PMC numbers collected on other code)."""
     import hashlib
     h = hashlib.sha256()
-    for d in sorted(LIB_DEPS):
+    for d in sorted(KERNEL_DEPS):
         with open(os.path.join(CSRC, d), "rb") as f:
             h.update(d.encode() + b"\0" + f.read())
     h.update(flags_string().encode())

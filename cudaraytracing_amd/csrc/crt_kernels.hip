@@ -98,8 +98,10 @@ struct LParams {
     uint32_t n_mats;
     FastDiv lsn_div, nslots_div, tiles_x_div;
     unsigned int* item_next; // [ITEM_SHARDS * ITEM_STRIDE] cursors, relative to the shard start
-    float4* L;              // per work item radiance
+    float4* L;              // per work item radiance (crt_intersect: per query ray (t, bits(triangle), -, -))
     unsigned long long* counters;
+    const float4* q_o;      // crt_intersect: origins / normalised directions of the query rays (work item = ray index)
+    const float4* q_d;
 };
 
 struct TParams {
@@ -738,8 +740,10 @@ __device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint3
     L.sp = 0;
     // rays with a zero / denormal direction component (inv_dir not finite) can put NaNs into the
     // slab test; they walk the reference topology, whose box tests are the reference's own (crt_accel.h)
+    // (the same predicate as k_mega3's start_ray: a non-finite ORIGIN puts NaNs into the min / max form of the slab test too)
     const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
-    L.ref = (MODE == 0 && finite_inv) ? sc.root_fast : sc.root_exact;
+    const bool finite_o = absf(L.r.o.x) <= FLT_MAX && absf(L.r.o.y) <= FLT_MAX && absf(L.r.o.z) <= FLT_MAX;
+    L.ref = (MODE == 0 && finite_inv && finite_o) ? sc.root_fast : sc.root_exact;
     if (L.any_hit) {
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) return TR_IDLE;
@@ -925,13 +929,14 @@ struct MParams {
 #define RF_EXACT 0x10000000u   /* reference box arithmetic (non-finite operands) */
 #define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
 #define RF_SKIP 0x40000000u    /* (NewRay only) next-event sample with a zero contribution: answered without traversal */
+#define RF_QUERY 0x80000000u   /* crt_intersect: a bare closest-hit query; its result goes straight back to LC */
 #ifndef POOL3_P
 #define POOL3_P 148         /* 148 x 64 B + rings = 10 212 B: 16 waves per CU */
 #endif
 #define POOL3_QCAP ((POOL3_P + 3) & ~3) /* ring capacity (any number >= POOL3_P: indices wrap by compare, not by mask); ids fit a byte */
-#if POOL3_P > 256
-#error "ray ids of a pool must fit a byte"
-#endif
+static_assert(POOL3_P <= 256, "ray ids of a pool must fit a byte (ring entries are uint8_t)");
+static_assert(POOL3_QCAP >= POOL3_P, "a ring must hold every ray of the pool");
+#define CRT_MEGA3_MAX_STACK 255 /* the traversal stack depth is kept in 8 bits of the record's word D */
 #define CRT_MEGA3_MAX_LEAF 65535 /* best-triangle offset inside its leaf is kept in 16 bits */
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1010,13 +1015,15 @@ __device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, 
 
 // Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
 // or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
+template <bool QUERY = false>
 __device__ __forceinline__ uint32_t route_done(uint32_t flags)
 {
+    if (QUERY) return PH3_LC;
     return (flags & RF_SHADOW) ? ((flags & RF_LAST) ? PH3_LB : PH3_LA) : ((flags & (RF_PROBE | RF_HASHIT)) ? PH3_LA : PH3_LC);
 }
 
 // Writes the new ray into the pool record `id` and returns its first phase.
-template <int MODE>
+template <int MODE, bool QUERY = false>
 __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
 {
     cnt.rays++;
@@ -1050,7 +1057,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
     S.C[id] = make_float4(inv.x, inv.y, inv.z, __int_as_float(ref));
     S.D[id] = flags;
-    if (answered) return route_done(flags);
+    if (answered) return route_done<QUERY>(flags);
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
 }
 
@@ -1308,6 +1315,24 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
     }
 }
 
+// crt_intersect's form of LC: the work items are query rays (origin, normalised direction); a finished ray's record holds
+// the answer (T = distance or FLT_MAX, best triangle or -1), which goes to L[ray].  The rays walk exactly the traversal phases
+// of the render (4-wide tree, packed pair tests, tie rule, pruning) -- DeviceBVH::intersect (DeviceBVH.cuh:128-170) per ray.
+__device__ __forceinline__ bool query_C(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
+{
+    const Pool& pl = P.pool;
+    const float4 la = pl.la[g];
+    const uint4 idv = pl.id[g];
+    if (((__float_as_uint(la.w) >> 8) & 15u) != ST_NEW) P.L[idv.z] = make_float4(qa.w, qb.w, 0.0f, 0.0f);
+    const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
+    if (item == ITEM_NONE) return false;
+    pl.id[g] = make_uint4(0u, 0u, item, 0u);
+    pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8));
+    const float4 o = P.q_o[item], d = P.q_d[item];
+    nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = RF_QUERY;
+    return true;
+}
+
 // Both child boxes of an inner node at once (hit_AABB, DeviceBVH.cuh:87-126); lane .x = left child, .y = right child.
 // Node layout: crt_device.h (nodes3).  exact = reference arithmetic (sign-selected planes, x<y?x:y minima) for rays with
 // non-finite operands; otherwise minima / maxima of the two plane distances, which are the same numbers.
@@ -1500,7 +1525,7 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
-template <int MODE, bool STATS, bool ALL = false>
+template <int MODE, bool STATS, bool ALL = false, bool QUERY = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mega3(const MParams3 M3)
 {
     __shared__ Pool3Lds S;
@@ -1647,7 +1672,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 S.C[id].w = __int_as_float(ref);
                 S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
                 if (STATS && done && (qd & RF_HASHIT)) tc.hits++; // (an any-hit ray that records a hit ends in the leaf step)
-                nph = done ? route_done(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                nph = done ? route_done<QUERY>(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
             }
             PUSH3()
             CRT_SEC3(5, nph)
@@ -1705,7 +1730,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 S.C[id].w = __int_as_float(ref);
                 S.D[id] = qd;
                 if (STATS && done && tri >= 0) tc.hits++;
-                nph = done ? route_done(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                nph = done ? route_done<QUERY>(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
             }
             PUSH3()
         } else if (act == PH3_LA) {
@@ -1740,7 +1765,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                if (logic_C(Pl, tl, g, cnt, nr)) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
+                if (QUERY ? query_C(Pl, g, S.A[id], S.B[id], nr) : logic_C(Pl, tl, g, cnt, nr))
+                    nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
             }
             PUSH3()
         }
@@ -2105,6 +2131,29 @@ int validate_desc(const crt_scene_desc* d)
             if (n.lc < 0 || n.rc < 0 || (uint32_t)n.lc >= i || (uint32_t)n.rc >= i) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: inner node children must precede it (post-order)");
         }
     }
+    {
+        // every node must hang under the root exactly once (the reference builder emits a tree in post-order, BVH.h:37-84), and the
+        // leaves must own disjoint triangle ranges: the FAST traversal builds its own tree over ALL leaves of the description, so a
+        // leaf the reference topology cannot reach, or two leaves sharing triangles, would make the two modes disagree
+        std::vector<uint8_t> seen(d->n_nodes, 0), owned(d->n_tris, 0);
+        std::vector<int32_t> todo(1, d->root);
+        uint32_t visited = 0;
+        while (!todo.empty()) {
+            const int32_t i = todo.back();
+            todo.pop_back();
+            if (seen[i]) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: a node is reachable from the root more than once");
+            seen[i] = 1;
+            visited++;
+            const crt_bvh_node& n = d->nodes[i];
+            if (n.lc < 0 && n.rc < 0) {
+                for (uint32_t k = 0; k < n.n; k++) {
+                    if (owned[(uint32_t)n.it + k]) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: two leaves share a triangle");
+                    owned[(uint32_t)n.it + k] = 1;
+                }
+            } else { todo.push_back(n.lc); todo.push_back(n.rc); }
+        }
+        if (visited != d->n_nodes) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: nodes that the root does not reach");
+    }
     for (uint32_t i = 0; i < d->n_tris; i++)
         if (d->tris[i].material < 0 || (uint32_t)d->tris[i].material >= d->n_materials) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: triangle material index out of range");
     for (uint32_t i = 0; i < d->n_light_tris; i++)
@@ -2138,6 +2187,12 @@ uint32_t env_u32(const char* name, uint32_t dflt)
     long x = std::strtol(v, nullptr, 10);
     return x > 0 ? (uint32_t)x : dflt;
 }
+
+// Which pipeline renders: 4 = k_mega3 (the product), 2 = the wavefront pipeline (k_logic + k_trace).  k_mega3 keeps the best
+// triangle's offset inside its leaf in 16 bits, addresses nodes and leaf records with 32-bit byte offsets and the traversal stack
+// depth in 8 bits; scenes beyond any of these fall back to the wavefront pipeline, which has no such limits.  The CRT_TEST_*
+// variables lower the limits so that the tests can force each fallback on a small scene.
+uint32_t choose_pipeline(const crt_scene* sc);
 
 const uint64_t kMaxChunkItems = 1ull << 30; // paths per chunk (17 GB of per-path radiance: sized for 288 GB of HBM, every launch ends with a 2 ms tail)
 
@@ -2244,11 +2299,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
-        if (pipeline != 2) pipeline = 4;
-        if (pipeline == 4 && sc->max_leaf > CRT_MEGA3_MAX_LEAF) pipeline = 2; // k_mega3 keeps the best triangle's offset in its leaf in 16 bits
-        if (pipeline == 4 && (sc->nodes4.n * sizeof(float4) >= (1ull << 32) || sc->leaf_geo.n * sizeof(float4) >= (1ull << 32)))
-            pipeline = 2; // k_mega3 addresses nodes and leaf records with 32-bit byte offsets (33 M nodes / 53 M records)
+        const uint32_t pipeline = choose_pipeline(sc);
         if (pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
@@ -2517,6 +2568,20 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
     } catch (const HipFail& f) {
         return fail_hip(f);
     }
+}
+
+uint32_t choose_pipeline(const crt_scene* sc)
+{
+    uint32_t pipeline = env_u32("CRT_PIPELINE", 4);
+    if (pipeline != 2) pipeline = 4;
+    const uint64_t max_leaf = env_u32("CRT_TEST_MAX_LEAF", CRT_MEGA3_MAX_LEAF);
+    const uint64_t max_bytes = std::getenv("CRT_TEST_MAX_BYTES") ? (uint64_t)env_u32("CRT_TEST_MAX_BYTES", 0xffffffffu) : (1ull << 32);
+    const uint32_t max_stack = env_u32("CRT_TEST_MAX_STACK", CRT_MEGA3_MAX_STACK);
+    if (pipeline == 4 && sc->max_leaf > max_leaf) pipeline = 2;
+    if (pipeline == 4 && (sc->nodes4.n * sizeof(float4) >= max_bytes || sc->nodes3.n * sizeof(float4) >= max_bytes || sc->leaf_geo.n * sizeof(float4) >= max_bytes))
+        pipeline = 2; // (33 M nodes / 53 M records)
+    if (pipeline == 4 && (uint32_t)sc->stack_cap > max_stack) pipeline = 2; // a deeper stack would spill into the flag bits of word D
+    return pipeline;
 }
 
 } // namespace
@@ -2821,6 +2886,42 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
         pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.res = sc->p_res.p; pool.n = n;
         hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p);
         HIP_CHECK(hipGetLastError());
+        if (choose_pipeline(sc) == 4) {
+            // the rays walk the traversal phases of the render kernel itself (k_mega3 in query form: work item = ray)
+            const bool reference = traversal == CRT_TRAVERSAL_REFERENCE;
+            int per_cu = 1;
+            if ((reference ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<1, false, false, true>, 64, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<0, false, false, true>, 64, 0)) != hipSuccess || per_cu < 1) per_cu = 1;
+            const uint32_t pool_p = (uint32_t)POOL3_P;
+            const uint32_t blocks = std::min<uint32_t>((n + pool_p - 1) / pool_p, (uint32_t)(sc->n_cus * per_cu));
+            const uint32_t lanes = blocks * pool_p;
+            sc->p_la.ensure(lanes); sc->p_id.ensure(lanes); sc->L.ensure(n);
+            sc->spill[0].ensure((size_t)std::max(1, sc->stack_cap - POOL_LV) * lanes);
+            MParams3 M3;
+            std::memset(&M3, 0, sizeof(M3));
+            LParams& P = M3.M.P;
+            P.sc = sc->dev;
+            P.pool.la = sc->p_la.p; P.pool.id = sc->p_id.p; P.pool.n = lanes;
+            P.n_items = n;
+            P.items_per_shard = ((n + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
+            P.item_next = sc->item_next.p; P.L = sc->L.p; P.counters = sc->counters.p;
+            P.q_o = sc->p_ro.p; P.q_d = sc->p_rd.p;
+            P.nslots = 1; P.nslots_div = make_fastdiv(1); P.tiles_x = 1; P.tiles_x_div = make_fastdiv(1); P.lsn_div = make_fastdiv(1);
+            M3.M.sc = sc->dev; M3.M.counters = sc->counters.p; M3.M.spill_stride = lanes; M3.M.stack_cap = POOL_LV;
+            M3.spill = (int*)sc->spill[0].p;
+            HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), nullptr));
+            if (reference) hipLaunchKernelGGL((k_mega3<1, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
+            else hipLaunchKernelGGL((k_mega3<0, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipDeviceSynchronize());
+            std::vector<float4> res(n);
+            HIP_CHECK(hipMemcpy(res.data(), sc->L.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < n; i++) {
+                out_t[i] = res[i].x;
+                std::memcpy(&out_tri[i], &res[i].y, 4);
+            }
+            return CRT_OK;
+        }
         TraceSetup TS = make_trace_setup(sc, pool, traversal == CRT_TRAVERSAL_REFERENCE, false);
         launch_trace_pass(sc, TS, nullptr);
         HIP_CHECK(hipGetLastError());

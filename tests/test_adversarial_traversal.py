@@ -1,0 +1,295 @@
+"""Adversarial probes of CRT_TRAVERSAL_FAST's pruning rule (csrc/crt_trace.h: prune_bound).
+
+FAST skips a box whose slab entry distance lies beyond best_t + (|best_t| * 1e-3 + 1e-3).  That is exact as long as the
+Moeller-Trumbore distance of every triangle inside the box agrees with the box's own entry distance to within the slack;
+Moeller-Trumbore has no bounded relative error for rays that graze a triangle's plane (determinant -> 0), for sliver
+triangles, or far from the origin (cancellation in o - v1), so the contract of include/crt.h is "identical to REFERENCE on
+every probe of this file and on every scene of the suite", not a theorem.  These tests aim at exactly those cases and
+compare FAST with the exhaustive REFERENCE traversal (GPU) and with the oracle, closest-hit ids and distance bits
+included."""
+import os
+
+import numpy as np
+import pytest
+
+import cudaraytracing_amd as crt
+import oracle_lib as O
+import util
+from test_gpu_parity import _write_box_scene, _write_soup_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(obj, mtl, thresh, w=48, h=36):
+    scene = crt.Scene(w, h)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(thresh)
+    osc = O.OracleScene([(obj, mtl)], thresh)
+    assert scene.nodes().tobytes() == osc.nodes().tobytes()
+    return scene, osc
+
+
+def _check_rays(r, osc, o, d):
+    otri, ot, _ = osc.intersect(o, d)
+    out = {}
+    for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        tri, t = r.intersect(o, d, traversal=mode)
+        out[mode] = (tri, t)
+        bad = np.nonzero((tri != otri) | (util.bits(t) != util.bits(ot)))[0]
+        assert bad.size == 0, (mode, bad[:8], tri[bad[:8]], otri[bad[:8]], t[bad[:8]], ot[bad[:8]])
+    return otri, ot
+
+
+def _grazing_rays(tris, rng, n_per, angles):
+    """Rays that cross triangle planes at the given (tiny) angles, aimed at a point inside the triangle, from both sides,
+    from near and far; plus rays lying exactly in the plane (determinant exactly or nearly zero)."""
+    o_list, d_list = [], []
+    for v in tris:
+        e1, e2 = v[1] - v[0], v[2] - v[0]
+        n = np.cross(e1, e2)
+        ln = np.linalg.norm(n)
+        if ln == 0:
+            continue
+        n /= ln
+        for _ in range(n_per):
+            a, b = rng.uniform(0.05, 0.9), rng.uniform(0.05, 0.9)
+            if a + b > 0.95:
+                a, b = 0.3, 0.3
+            p = v[0] + a * e1 + b * e2
+            tdir = np.cos(rng.uniform(0, 2 * np.pi)) * e1 / np.linalg.norm(e1) + np.sin(rng.uniform(0, 2 * np.pi)) * np.cross(n, e1) / np.linalg.norm(e1)
+            tdir /= np.linalg.norm(tdir)
+            for th in angles:
+                for sgn in (1.0, -1.0):
+                    d = np.cos(th) * tdir + sgn * np.sin(th) * n
+                    s = rng.choice([0.01, 0.5, 3.0, 40.0])
+                    o_list.append(p - s * d)
+                    d_list.append(d)
+    return np.asarray(o_list, dtype=np.float32), np.asarray(d_list, dtype=np.float32)
+
+
+def _soup_triangles(obj):
+    vs, fs = [], []
+    for line in open(obj):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            vs.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            fs.append([int(x.split("/")[0]) - 1 for x in t[1:4]])
+    vs = np.asarray(vs, dtype=np.float64)
+    return [vs[f] for f in fs]
+
+
+@pytest.mark.parametrize("thresh", [1, 2, 4])
+def test_rays_grazing_triangle_planes(tmp_path, thresh):
+    obj, mtl = _write_soup_scene(str(tmp_path), n=300, dup=30, degenerate=10)
+    scene, osc = _load(obj, mtl, thresh)
+    r = crt.Render(scene, 1, 0.6, 1)
+    try:
+        rng = np.random.RandomState(7)
+        tris = _soup_triangles(obj)
+        pick = [tris[i] for i in rng.choice(len(tris), 160, replace=False)]
+        o, d = _grazing_rays(pick, rng, 3, [0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2])
+        otri, ot = _check_rays(r, osc, o, d)
+        assert (otri >= 0).sum() > o.shape[0] // 4  # the probes do hit things
+    finally:
+        r.free()
+
+
+def _write_sliver_scene(d, n=500, seed=5):
+    """The room with a cloud of sliver triangles in it: aspect ratios 1e3 ... 1e7 (two long edges, one of 1e-3 ... 1e-7),
+    needles with nearly collinear vertices, and slivers that share their long edge (equal distances along it)."""
+    rng = np.random.RandomState(seed)
+    obj, mtl = _write_box_scene(d, n_side=4)
+    tris = []
+    for i in range(n):
+        c = rng.uniform(1.5, 8.5, 3)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        w = np.cross(u, rng.normal(size=3)); w /= np.linalg.norm(w)
+        length = rng.uniform(0.5, 4.0)
+        width = 10.0 ** rng.uniform(-7, -3)
+        a = c - 0.5 * length * u
+        b = c + 0.5 * length * u
+        cc = c + rng.uniform(-0.4, 0.4) * length * u + width * w
+        tris.append(np.stack([a, b, cc]))
+        if i % 5 == 0:  # a second sliver on the same long edge, folded the other way
+            tris.append(np.stack([a, b, c - width * w]))
+    with open(obj) as f:
+        nv = sum(1 for line in f if line.startswith("v "))
+    with open(obj, "a") as o:
+        o.write("usemtl floor\n")
+        for t in tris:
+            for v in t.astype(np.float32):
+                o.write("v %.9g %.9g %.9g\nvn 0 1 0\nvt 0 0\n" % tuple(v))
+            o.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (nv + 1, nv + 1, nv + 1, nv + 2, nv + 2, nv + 2, nv + 3, nv + 3, nv + 3))
+            nv += 3
+    return obj, mtl, tris
+
+
+@pytest.mark.parametrize("thresh", [1, 2])
+def test_sliver_triangles(tmp_path, thresh):
+    obj, mtl, tris = _write_sliver_scene(str(tmp_path))
+    scene, osc = _load(obj, mtl, thresh, 64, 48)
+    eye = np.array([5.0, 5.0, 0.5], dtype=np.float32)
+    iv = crt.get_inverse_view_matrix(eye, [5.0, 4.5, 9.0], [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, 2, 0.6, 2)
+    r.seed = 9
+    try:
+        orgb, omean, _, st = osc.render(eye, iv, fov, 64, 48, 2, 0.6, 2, seed=9)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), mode
+            assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
+        rng = np.random.RandomState(3)
+        # rays aimed along the slivers (at points of their long edges), across them, and grazing their planes
+        o_list, d_list = [], []
+        for t in tris[::2]:
+            for _ in range(4):
+                p = t[0] + rng.uniform(0.02, 0.98) * (t[1] - t[0])
+                src = rng.uniform(0.5, 9.5, 3)
+                o_list.append(src); d_list.append(p - src)
+        o = np.asarray(o_list, dtype=np.float32); d = np.asarray(d_list, dtype=np.float32)
+        _check_rays(r, osc, o, d)
+        og, dg = _grazing_rays(tris[::7], rng, 2, [0.0, 1e-6, 1e-4, 1e-2])
+        _check_rays(r, osc, og, dg)
+    finally:
+        r.free()
+
+
+@pytest.mark.parametrize("offset", [1.0e4, 1.0e6, 3.0e7])
+def test_scene_far_from_the_origin(tmp_path, offset):
+    """Every coordinate translated by `offset` (at 3e7 a float's spacing is 2: vertices collapse onto a coarse lattice,
+    o - v1 cancels to a few bits): FAST must still return what REFERENCE returns."""
+    obj, mtl = _write_soup_scene(str(tmp_path), n=250, dup=25, degenerate=10)
+    lines = open(obj).read().split("\n")
+    with open(obj, "w") as f:
+        for line in lines:
+            if line.startswith("v "):
+                x, y, z = (np.float32(float(v) + offset) for v in line.split()[1:4])
+                line = "v %.9g %.9g %.9g" % (x, y, z)
+            f.write(line + "\n")
+    w, h, spp = 48, 36, 2
+    scene, osc = _load(obj, mtl, 2, w, h)
+    eye = (np.array([5.0, 5.0, 0.5]) + offset).astype(np.float32)
+    iv = crt.get_inverse_view_matrix(eye, (np.array([5.0, 4.5, 9.0]) + offset).astype(np.float32), [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, spp, 0.6, 2)
+    r.seed = 5
+    try:
+        orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (offset, mode)
+            assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
+        rng = np.random.RandomState(2)
+        n = 8192
+        o = (rng.uniform(0.5, 9.5, (n, 3)) + offset).astype(np.float32)
+        d = rng.normal(size=(n, 3)).astype(np.float32)
+        _check_rays(r, osc, o, d)
+    finally:
+        r.free()
+
+
+def test_grazing_rays_on_the_shipped_scenes():
+    """The same probe on the two benchmark scenes: rays grazing randomly chosen triangles of cornell-box and veach-mis."""
+    for name in ("cornell-box", "veach-mis"):
+        t = util.task(name)
+        osc = util.oracle_scene(name)
+        r = crt.Render(util.host_scene(name), 1, t.P_RR, t.light_sample_n)
+        try:
+            rng = np.random.RandomState(11)
+            tr = osc.tris()
+            idx = rng.choice(len(tr), 400, replace=False)
+            tris = [np.stack([tr["v1"][i], tr["v2"][i], tr["v3"][i]]).astype(np.float64) for i in idx]
+            o, d = _grazing_rays(tris, rng, 2, [0.0, 1e-6, 1e-4, 1e-2])
+            scale = float(np.abs(tr["v1"]).max())
+            o = (o.astype(np.float64)).astype(np.float32)
+            _check_rays(r, osc, o, d)
+            assert scale > 0
+        finally:
+            r.free()
+
+
+# ----------------------------------------------------------------------------------------------
+# The fallbacks of the pipeline choice (csrc/crt_kernels.hip: choose_pipeline): scenes beyond k_mega3's 16-bit leaf offsets,
+# 32-bit byte offsets or 8-bit stack depth render with the wavefront pipeline.  The CRT_TEST_* hooks lower each limit so
+# that an ordinary scene trips it; the frame must not change (and the many trace launches show which pipeline ran).
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hook,value", [("CRT_TEST_MAX_LEAF", "1"), ("CRT_TEST_MAX_BYTES", "4096"), ("CRT_TEST_MAX_STACK", "3"),
+                                        ("CRT_PIPELINE", "2")])
+def test_fallbacks_to_the_wavefront_pipeline(tmp_path, monkeypatch, hook, value):
+    obj, mtl = _write_soup_scene(str(tmp_path), n=200, dup=20, degenerate=10)
+    w, h, spp = 48, 36, 2
+    scene, osc = _load(obj, mtl, 2, w, h)
+    eye = np.array([5.0, 5.0, 0.5], dtype=np.float32)
+    iv = crt.get_inverse_view_matrix(eye, [5.0, 4.5, 9.0], [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, spp, 0.6, 2)
+    r.seed = 5
+    try:
+        orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
+        r.run_view(eye, iv, fov)
+        assert r.stats["kernel_launches"] == 1  # k_mega3: one launch per frame
+        monkeypatch.setenv(hook, value)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert r.stats["kernel_launches"] > 1, hook  # rounds of k_logic + k_trace
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (hook, mode)
+            assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
+        rng = np.random.RandomState(4)
+        o = rng.uniform(0.5, 9.5, (4096, 3)).astype(np.float32)
+        d = rng.normal(size=(4096, 3)).astype(np.float32)
+        _check_rays(r, osc, o, d)  # crt_intersect follows the same choice (k_trace)
+    finally:
+        r.free()
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e12, 1e17])
+def test_extreme_scales_on_the_wavefront_pipeline(tmp_path, monkeypatch, scale):
+    """the wavefront fallback must send rays with a non-finite ORIGIN (overflowed hit positions) down the
+    reference arithmetic too, as k_mega3's start_ray does."""
+    monkeypatch.setenv("CRT_PIPELINE", "2")
+    obj, mtl = _write_soup_scene(str(tmp_path), n=200, dup=20, degenerate=10)
+    lines = open(obj).read().split("\n")
+    with open(obj, "w") as f:
+        for line in lines:
+            if line.startswith("v "):
+                x, y, z = (np.float32(float(v) * scale) for v in line.split()[1:4])
+                line = "v %.9g %.9g %.9g" % (x, y, z)
+            f.write(line + "\n")
+    w, h, spp = 48, 36, 2
+    scene, osc = _load(obj, mtl, 2, w, h)
+    eye = (np.array([5.0, 5.0, 0.5]) * scale).astype(np.float32)
+    iv = crt.get_inverse_view_matrix(eye, (np.array([5.0, 4.5, 9.0]) * scale).astype(np.float32), [0.0, 1.0, 0.0])
+    fov = crt.fov_to_radians(75.0)
+    r = crt.Render(scene, spp, 0.6, 2)
+    r.seed = 5
+    try:
+        orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+            r.traversal = mode
+            rgb = r.run_view(eye, iv, fov)
+            assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (scale, mode)
+            assert np.array_equal(rgb, orgb) and r.stats["rays"] == st["rays"]
+    finally:
+        r.free()
+
+
+def test_scene_description_must_be_one_tree():
+    """crt_scene_create rejects descriptions whose leaves the root cannot reach (the FAST tree is built over all leaves)."""
+    import ctypes as C
+    from cudaraytracing_amd import _capi as capi
+    sc = util.host_scene("veach-mis")
+    d = sc.desc()
+    nodes = sc.nodes().copy()
+    bad = capi.SceneDesc()
+    C.memmove(C.byref(bad), C.byref(d), C.sizeof(capi.SceneDesc))
+    bad.root = int(nodes[sc.root]["lc"])  # a proper subtree: the other half of the leaves is unreachable
+    h = C.c_void_p()
+    assert capi.lib().crt_scene_create(C.byref(bad), 0, C.byref(h)) == -1
+    assert b"does not reach" in capi.lib().crt_last_error()

@@ -1,24 +1,38 @@
 #!/bin/bash
 # Collects the judged profile artefacts on the GPU box into gpurun_out/profiles_<tag>/:
-#   kernel stats of the default bench.py command, and HBM traffic (FETCH_SIZE / WRITE_SIZE in
-#   separate passes, as MI355X_MICROARCH.md prescribes) + SQ counters of a full-size frame.
-tag=${1:-r01}
+#   stats/   rocprofv3 --kernel-trace --stats of the default bench.py command
+#   c2_*/    PMC passes of one full-size C2 frame (cornell-box 800x600 spp 512), one --pmc group per run, FETCH_SIZE and
+#            WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes (never combined with trace domains)
+#   c3_*/    the same groups on one C3 frame (veach-mis 800x600 spp 1024)
+#   pmc_latest.json  per-launch counters of both workloads STAMPED with the hash of the kernel sources + build flags
+#                    (cudaraytracing_amd.build.source_hash); bench.py drops the numbers when the hash differs
+# usage: tools/collect_profiles.sh <tag> [valu_cycles_per_instr]
+tag=${1:-r02}
+cyc=${2:-2.0}
 out=gpurun_out/profiles_$tag
 export TMPDIR=/tmp
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_stats.log 2>&1 || echo "stats pass failed"
-i=0
-while read -r counters; do
-  i=$((i+1))
-  timeout 200 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $out/pmc$i -- python3 tools/perf_probe.py --spp 512 --reps 1 > $out/pmc$i.log 2>&1 || echo "pmc pass $i failed"
-done <<'EOC'
-FETCH_SIZE
-WRITE_SIZE
-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY
-SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA
-TCC_HIT_sum TCC_MISS_sum
-GRBM_GUI_ACTIVE GRBM_TA_BUSY
-EOC
-python3 tools/pmc_summary.py $out > $out/summary.json
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c3 > $out/bench_stats.log 2>&1 || echo "stats pass failed"
+groups=(
+"FETCH_SIZE"
+"WRITE_SIZE"
+"SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY"
+"SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM"
+"TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
+"SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"
+"GRBM_GUI_ACTIVE GRBM_TA_BUSY"
+)
+for wl in c2 c3; do
+  if [ $wl = c2 ]; then probe="--scene cornell-box --spp 512"; else probe="--scene veach-mis --spp 1024"; fi
+  i=0
+  for counters in "${groups[@]}"; do
+    i=$((i+1))
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d $out/${wl}_pmc$i -- python3 tools/perf_probe.py $probe --reps 1 > $out/${wl}_pmc$i.log 2>&1 || echo "pmc pass $wl $i failed"
+  done
+  mkdir -p $out/$wl && rm -rf $out/$wl/* && mv $out/${wl}_pmc* $out/$wl/ 2>/dev/null
+  python3 tools/pmc_summary.py $out/$wl > $out/${wl}_summary.json
+done
+python3 tools/pmc_summary.py $out/stats > $out/stats_summary.json
 grep -h '"metric"' $out/bench_stats.log | tail -1 > $out/bench_line.json
+python3 tools/make_pmc_json.py $out $cyc > $out/pmc_latest.json
 ls $out

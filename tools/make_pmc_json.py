@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Builds pmc_latest.json (read by bench.py for the roofline) from the summaries tools/collect_profiles.sh writes.
+
+Per workload (c2 = cornell-box 800x600 spp 512, c3 = veach-mis 800x600 spp 1024; one frame = one launch of k_mega3) the raw
+counter sums of the dominant kernel, collected with one rocprofv3 --pmc pass per group (FETCH_SIZE and WRITE_SIZE in
+separate passes; their KiB unit and the gfx950 read correction are applied by the reader: bytes = 2 x FETCH_SIZE x 1024 +
+WRITE_SIZE x 1024, MI355X_MICROARCH.md "HBM").  The file is stamped with the hash of the kernel sources and build flags it was
+collected on.  usage: make_pmc_json.py <profiles dir> [valu cycles per instruction]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cudaraytracing_amd import build as B
+
+root = sys.argv[1]
+cyc = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+res = {"src_hash": B.source_hash(), "build_flags": B.built_flags(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
+       "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <one group> -- python3 tools/perf_probe.py --scene S --spp N --reps 1",
+       "valu_cycles_per_instr_source": "tools/valu_issue_bench.hip (independent v_add_f32 / v_pk_* streams, 4 waves per SIMD)",
+       "workloads": {}}
+for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x600 spp=1024")):
+    f = os.path.join(root, wl + "_summary.json")
+    if not os.path.exists(f):
+        continue
+    d = json.load(open(f))
+    ks = [n for n in d if n.startswith("k_mega3<0, false, false>") or n.startswith("k_mega3<0, false>")]
+    if not ks:
+        continue
+    v = dict(d[ks[0]])
+    v.pop("stats", None)
+    w = {"workload": desc + ", 1 MI355X, one frame = 1 launch", "kernel": ks[0].replace(", ", ","), "launches": 1,
+         "valu_cycles_per_instr": cyc, "collected": res["collected"]}
+    w.update(v)
+    if v.get("SQ_INSTS_VALU"):
+        w["salu_per_valu"] = round(v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"], 4)
+    if v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]) > 0:
+        w["tcc_miss_frac"] = round(v["TCC_MISS_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
+    if v.get("SQ_LDS_BANK_CONFLICT") is not None and v.get("SQ_LDS_IDX_ACTIVE"):
+        w["lds_conflict_frac"] = round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 4)
+    res["workloads"][wl] = w
+# average launch duration of the profiled bench run, for the agreement check against bench.py's HIP-event time
+f = os.path.join(root, "stats_summary.json")
+if os.path.exists(f):
+    d = json.load(open(f))
+    for n, v in d.items():
+        if n.startswith("k_mega3<0, false, false>") and "stats" in v and "c2" in res["workloads"]:
+            res["workloads"]["c2"]["avg_launch_ms"] = round(float(v["stats"]["AverageNs"]) / 1e6, 3)
+            res["workloads"]["c2"]["stats_calls"] = int(v["stats"]["Calls"])
+print(json.dumps(res, indent=1))

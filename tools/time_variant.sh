@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/time_variant.sh "<flags>" ...   timing only (C2 and veach spp 256) of builds with extra compile flags; restores the default build
+trap 'python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1' EXIT  # always leave the default build in the tree
 for flags in "$@"; do
   CRT_EXTRA_CXXFLAGS="$flags" python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
   echo "== $flags"

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds libcrt.so with extra compile flags on the GPU box, runs the parity tests of the default pipeline and a timing probe.
 # usage: tools/try_variant.sh "<flags>" [spp]
+trap 'python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1' EXIT  # always leave the default build in the tree
 flags="$1"; spp=${2:-512}
 CRT_EXTRA_CXXFLAGS="$flags" python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1 || { echo "build failed: $flags"; exit 1; }
 echo "== $flags"

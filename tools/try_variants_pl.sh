@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/try_variants_pl.sh "P:LV ..."   builds each (pool size, LDS stack levels) variant of k_mega3 and times C2 / veach
+trap 'python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1' EXIT  # always leave the default build in the tree
 for v in $1; do
   P=${v%%:*}; LV=${v##*:}
   CRT_EXTRA_CXXFLAGS="-DPOOL3_P=$P -DPOOL_LV=$LV" python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
