@@ -118,7 +118,7 @@ def load_pmc(workload_key):
 def bounds_from_pmc(pmc, k_s):
     """The three candidate bounds for one launch of duration k_s seconds; every fraction is <= 1 by construction."""
     out = {}
-    cyc = float(pmc.get("valu_cycles_per_instr", 2.0))
+    cyc = float(pmc.get("valu_cycles_per_instr", 3.35))
     if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
         traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
         out["hbm"] = {"achieved": round(traffic / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -128,6 +128,9 @@ def bounds_from_pmc(pmc, k_s):
         ach = pmc["SQ_INSTS_VALU"] / k_s / 1e9
         out["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
                              "cycles_per_instr": cyc, "lane_utilization": pmc.get("valu_lane_utilization")}
+        rng = pmc.get("valu_cycles_per_instr_range")
+        if rng:  # all unclassified instructions at the cheapest / the dearest measured issue cost
+            out["valu_issue"]["frac_range"] = [round(ach * rng[0] / (N_SIMDS * CLOCK_GHZ), 4), round(ach * rng[1] / (N_SIMDS * CLOCK_GHZ), 4)]
     if pmc.get("TCC_REQ_sum") is not None or (pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None):
         req = pmc.get("TCC_REQ_sum")
         if req is None:

@@ -21,6 +21,7 @@ groups=(
 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"
 "GRBM_GUI_ACTIVE GRBM_TA_BUSY"
+"SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INST_CYCLES_VALU"
 )
 for wl in c2 c3; do
   if [ $wl = c2 ]; then probe="--scene cornell-box --spp 512"; else probe="--scene veach-mis --spp 1024"; fi

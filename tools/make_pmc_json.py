@@ -15,8 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cudaraytracing_amd import build as B
 
+# the default render path: FAST traversal, no counting, zero-contribution samples answered without traversal, not the query form
+DEFAULT_KERNEL = ("k_mega3<0, false, false, false>", "k_mega3<0, false, false>", "k_mega3<0, false>")
 root = sys.argv[1]
-cyc = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
+# Issue cost of one wave64 vector instruction on one SIMD of gfx950, by counter class, measured with tools/valu_issue_bench.hip
+# (independent streams, 4 and 8 waves per SIMD; profiles/r02_valu_issue.json): v_add_f32 / v_mul_f32 / v_mov_b32 / v_and_b32 2.5
+# cycles, v_fma_f32 / v_fmac_f32 3.8-3.9, v_max_f32 / v_max3_f32 / v_pk_add_f32 / v_pk_mul_f32 / v_cndmask_b32 / v_mul_lo_u32 4.2,
+# v_cmp + v_cndmask 3.4 each, v_rcp_f32 / v_sqrt_f32 8.2.  INT32 and the unclassified rest (moves, compares, selects, min / max,
+# packed) mix 2.5- and 4.2-cycle members: priced at the midpoint, with the all-cheap / all-dear range kept beside it.
+COST = {"SQ_INSTS_VALU_ADD_F32": (2.5, 2.5, 2.5), "SQ_INSTS_VALU_MUL_F32": (2.5, 2.5, 2.5), "SQ_INSTS_VALU_FMA_F32": (3.9, 3.9, 3.9),
+        "SQ_INSTS_VALU_TRANS_F32": (8.2, 8.2, 8.2), "SQ_INSTS_VALU_INT32": (2.5, 3.35, 4.2), "SQ_INSTS_VALU_CVT": (4.2, 4.2, 4.2),
+        "other": (2.5, 3.35, 4.2)}
+cyc = float(sys.argv[2]) if len(sys.argv) > 2 else 3.35
 res = {"src_hash": B.source_hash(), "build_flags": B.built_flags(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
        "command": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <one group> -- python3 tools/perf_probe.py --scene S --spp N --reps 1",
        "valu_cycles_per_instr_source": "tools/valu_issue_bench.hip (independent v_add_f32 / v_pk_* streams, 4 waves per SIMD)",
@@ -26,7 +36,7 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
     if not os.path.exists(f):
         continue
     d = json.load(open(f))
-    ks = [n for n in d if n.startswith("k_mega3<0, false, false>") or n.startswith("k_mega3<0, false>")]
+    ks = [n for n in d if n in DEFAULT_KERNEL]
     if not ks:
         continue
     v = dict(d[ks[0]])
@@ -36,6 +46,16 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
     w.update(v)
     if v.get("SQ_INSTS_VALU"):
         w["salu_per_valu"] = round(v.get("SQ_INSTS_SALU", 0.0) / v["SQ_INSTS_VALU"], 4)
+        if all(v.get(c) is not None for c in COST if c != "other"):
+            rest = v["SQ_INSTS_VALU"] - sum(v[c] for c in COST if c != "other")
+            tot = [0.0, 0.0, 0.0]
+            for c, cost in COST.items():
+                n = rest if c == "other" else v[c]
+                for i in range(3):
+                    tot[i] += n * cost[i]
+            w["valu_cycles_per_instr"] = round(tot[1] / v["SQ_INSTS_VALU"], 3)
+            w["valu_cycles_per_instr_range"] = [round(tot[0] / v["SQ_INSTS_VALU"], 3), round(tot[2] / v["SQ_INSTS_VALU"], 3)]
+            w["valu_class_costs"] = {c: list(cost) for c, cost in COST.items()}
     if v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]) > 0:
         w["tcc_miss_frac"] = round(v["TCC_MISS_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
     if v.get("SQ_LDS_BANK_CONFLICT") is not None and v.get("SQ_LDS_IDX_ACTIVE"):
@@ -46,7 +66,7 @@ f = os.path.join(root, "stats_summary.json")
 if os.path.exists(f):
     d = json.load(open(f))
     for n, v in d.items():
-        if n.startswith("k_mega3<0, false, false>") and "stats" in v and "c2" in res["workloads"]:
+        if n in DEFAULT_KERNEL and "stats" in v and "c2" in res["workloads"]:
             res["workloads"]["c2"]["avg_launch_ms"] = round(float(v["stats"]["AverageNs"]) / 1e6, 3)
             res["workloads"]["c2"]["stats_calls"] = int(v["stats"]["Calls"])
 print(json.dumps(res, indent=1))
