@@ -214,6 +214,18 @@ class Render:
             self.frame_buffer, self.mean_buffer = rgb, mean
         return rgb
 
+    def preview(self, want_mean=False, width=None, height=None):
+        """Displayable frame of the progressive render in flight (crt_preview): returns (rgb (H, W, 3), mean or None, samples done).
+        Reads the accumulator only -- the final frame does not depend on previews."""
+        if not self._h:
+            raise RuntimeError("Render.preview after free()")
+        w, h = width or self.scene.width, height or self.scene.height
+        rgb = np.zeros((h, w, 3), dtype=np.uint8)
+        mean = np.zeros((h, w, 3), dtype=np.float32) if want_mean else None
+        done = C.c_uint32(0)
+        capi.check(capi.lib().crt_preview(self._h, capi.ptr(rgb), capi.ptr(mean), C.byref(done)), "crt_preview")
+        return rgb, mean, int(done.value)
+
     def run_view_device(self, eye_pos, inv_view_mat, fovY, d_rgb_ptr, d_mean_ptr=None, stream=None, rank=0, world=1,
                         tiled=False, want_stats=True, width=None, height=None):
         """Enqueues a render whose outputs stay in device memory (raw device pointers)."""
@@ -312,6 +324,9 @@ class MultiRender(Render):
     def run_view_range(self, *a, **k):
         raise NotImplementedError("progressive ranges are a single-device interface (crt_render_range)")
 
+    def preview(self, *a, **k):
+        raise NotImplementedError("previews are a single-device interface (crt_preview)")
+
     def run_view_device(self, *a, **k):
         raise NotImplementedError("MultiRender owns its device buffers (crt_multi_frame_device)")
 
@@ -322,6 +337,16 @@ class MultiRender(Render):
         if self._h:
             capi.lib().crt_multi_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def image_load(path):
+    """(x, y, comp, samples (y, x, comp) uint8) of a texture file as the reference's stbi_load(path, &x, &y, &comp, 0) returns them
+    (Loader.h:58): PNG, BMP, TGA."""
+    x, y, comp = C.c_int32(), C.c_int32(), C.c_int32()
+    capi.check(capi.lib().crt_image_load(os.fsencode(path), C.byref(x), C.byref(y), C.byref(comp), None, 0), "crt_image_load")
+    a = np.zeros((y.value, x.value, comp.value), dtype=np.uint8)
+    capi.check(capi.lib().crt_image_load(os.fsencode(path), C.byref(x), C.byref(y), C.byref(comp), capi.ptr(a), a.size), "crt_image_load")
+    return x.value, y.value, comp.value, a
 
 
 def shard_slots(width, height, rank, world):

@@ -4,7 +4,7 @@
 // dot = p0 + (p1 + p2), normalized = v / sqrt(squaredNorm) with true division,
 // cross as in OrthoMethods.h.  Compiled with -ffp-contract=off.
 #include "crt_host.hpp"
-#include "crt_png.h"
+#include "crt_image.h"
 
 #include <algorithm>
 #include <array>
@@ -304,8 +304,8 @@ const Loader::Texture& Loader::texture(const std::string& path) const
 {
     auto it = tex_cache_.find(path);
     if (it != tex_cache_.end()) return it->second;
-    crtpng::Image img;
-    const std::string err = crtpng::load(path, img);
+    crtimg::Image img;
+    const std::string err = crtimg::load(path, img);
     if (!err.empty()) throw Error(err.rfind("cannot open", 0) == 0 ? CRT_ERR_IO : CRT_ERR_UNSUPPORTED, "map_Kd: " + err);
     Texture t;
     t.x = img.width; t.y = img.height; t.comp = img.comp;
@@ -691,6 +691,19 @@ int crt_inverse_view(const float eye[3], const float lookat[3], const float up[3
 {
     if (!eye || !lookat || !up || !out) { g_last_error = "crt_inverse_view: null argument"; return CRT_ERR_INVALID_ARG; }
     crt::get_inverse_view_matrix(eye, lookat, up, out);
+    return CRT_OK;
+}
+int crt_image_load(const char* path, int32_t* x, int32_t* y, int32_t* comp, uint8_t* out, uint64_t cap)
+{
+    if (!path || !x || !y || !comp) { g_last_error = "crt_image_load: null argument"; return CRT_ERR_INVALID_ARG; }
+    crtimg::Image img;
+    const std::string err = crtimg::load(path, img);
+    if (!err.empty()) { g_last_error = "crt_image_load: " + err; return err.rfind("cannot open", 0) == 0 ? CRT_ERR_IO : CRT_ERR_UNSUPPORTED; }
+    *x = img.width; *y = img.height; *comp = img.comp;
+    if (out) {
+        if (cap < img.px.size()) { g_last_error = "crt_image_load: buffer too small"; return CRT_ERR_INVALID_ARG; }
+        std::memcpy(out, img.px.data(), img.px.size());
+    }
     return CRT_OK;
 }
 int crt_task_load(const char* path, crt_task* out)

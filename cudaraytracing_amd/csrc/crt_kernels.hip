@@ -1888,6 +1888,24 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
     if (A.out_mean) { A.out_mean[o * 3 + 0] = c.x; A.out_mean[o * 3 + 1] = c.y; A.out_mean[o * 3 + 2] = c.z; }
 }
 
+// crt_preview: the frame a progressive render would show now.  The accumulator holds sum_{k < done} L_k / spp (Render.cuh:348
+// with the samples so far); its estimate of the mean is that sum * spp / done.  Reads the accumulator only.
+__global__ __launch_bounds__(256) void k_preview(const AParams A, const float scale)
+{
+    uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= A.nslots) return;
+    uint32_t i = 0, j = 0;
+    const bool valid = slot_to_pixel(slot, A.rank, A.world, A.n_tiles, A.tiles_x, make_fastdiv_dev(A.tiles_x), A.width, A.height, i, j);
+    if (!valid && !A.tiled_output) return;
+    F3 c = f3(0.0f, 0.0f, 0.0f);
+    if (valid) c = f3(A.accum[slot] * scale, A.accum[A.nslots + slot] * scale, A.accum[2ull * A.nslots + slot] * scale);
+    const uint64_t o = A.tiled_output ? (uint64_t)slot : (uint64_t)j * A.width + i;
+    A.out_rgb[o * 3 + 0] = valid ? tonemap(c.x) : 0;
+    A.out_rgb[o * 3 + 1] = valid ? tonemap(c.y) : 0;
+    A.out_rgb[o * 3 + 2] = valid ? tonemap(c.z) : 0;
+    if (A.out_mean) { A.out_mean[o * 3 + 0] = c.x; A.out_mean[o * 3 + 1] = c.y; A.out_mean[o * 3 + 2] = c.z; }
+}
+
 // ------------------------------------------------------------ test kernels --
 // crt_intersect: loads n host rays into the first n pool slots (direction normalised as Ray's
 // constructor does, Ray.cuh:12-13) so that the production trace kernel answers them.
@@ -2013,6 +2031,8 @@ struct crt_scene {
     DevScene dev{};
     int stack_cap = 0;
     uint32_t n_tris = 0;
+    // progressive render in flight: what the accumulator holds (crt_preview)
+    struct { uint32_t samples = 0, spp = 0, width = 0, height = 0, rank = 0, world = 1, tiled = 0; } acc;
     std::vector<hipEvent_t> ev;
     ~crt_scene()
     {
@@ -2394,6 +2414,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
                 hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
                 HIP_CHECK(hipGetLastError());
+                sc->acc.samples = A.last_chunk ? 0u : s0 + ns; sc->acc.spp = prm->spp; sc->acc.width = prm->width; sc->acc.height = prm->height;
+                sc->acc.rank = prm->rank; sc->acc.world = prm->world; sc->acc.tiled = tiled ? 1u : 0u;
             }
             if (stats) {
                 HIP_CHECK(hipEventRecord(e3, st));
@@ -2546,6 +2568,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
             hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
             HIP_CHECK(hipGetLastError());
+            sc->acc.samples = A.last_chunk ? 0u : s0 + ns; sc->acc.spp = prm->spp; sc->acc.width = prm->width; sc->acc.height = prm->height;
+            sc->acc.rank = prm->rank; sc->acc.world = prm->world; sc->acc.tiled = tiled ? 1u : 0u;
         }
         if (stats) {
             HIP_CHECK(hipEventRecord(ev_end, st));
@@ -2863,6 +2887,53 @@ int crt_render_range(crt_scene* sc, const crt_camera* cam, const crt_params* prm
             HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, npix * 3, hipMemcpyDeviceToHost));
             if (out_mean) HIP_CHECK(hipMemcpy(out_mean, d_mean.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
         }
+        return CRT_OK;
+    } catch (const HipFail& f) {
+        return fail_hip(f);
+    }
+}
+
+int crt_preview_device(crt_scene* sc, void* d_rgb, void* d_mean, void* stream, uint32_t* samples_done)
+{
+    if (!sc || !d_rgb) return fail(CRT_ERR_INVALID_ARG, "crt_preview: null argument");
+    if (sc->acc.samples == 0) return fail(CRT_ERR_INVALID_ARG, "crt_preview: no progressive render in flight (submit a range that ends before spp first)");
+    try {
+        HIP_CHECK(hipSetDevice(sc->device));
+        Shard sh = make_shard(sc->acc.width, sc->acc.height, sc->acc.world);
+        AParams A;
+        std::memset(&A, 0, sizeof(A));
+        A.width = sc->acc.width; A.height = sc->acc.height; A.spp = sc->acc.spp;
+        A.rank = sc->acc.rank; A.world = sc->acc.world; A.tiles_x = sh.tiles_x; A.n_tiles = sh.n_tiles;
+        A.nslots = sh.nslots; A.tiled_output = sc->acc.tiled;
+        A.accum = sc->accum.p;
+        A.out_rgb = (uint8_t*)d_rgb; A.out_mean = (float*)d_mean;
+        const float scale = (float)sc->acc.spp / (float)sc->acc.samples;
+        hipLaunchKernelGGL(k_preview, dim3((sh.nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, scale);
+        HIP_CHECK(hipGetLastError());
+        if (samples_done) *samples_done = sc->acc.samples;
+        return CRT_OK;
+    } catch (const HipFail& f) {
+        return fail_hip(f);
+    }
+}
+
+int crt_preview(crt_scene* sc, uint8_t* out_rgb, float* out_mean, uint32_t* samples_done)
+{
+    if (!sc || !out_rgb) return fail(CRT_ERR_INVALID_ARG, "crt_preview: null argument");
+    if (sc->acc.samples == 0) return fail(CRT_ERR_INVALID_ARG, "crt_preview: no progressive render in flight (submit a range that ends before spp first)");
+    try {
+        HIP_CHECK(hipSetDevice(sc->device));
+        const uint64_t npix = sc->acc.tiled ? make_shard(sc->acc.width, sc->acc.height, sc->acc.world).nslots : (uint64_t)sc->acc.width * sc->acc.height;
+        DevBuf<uint8_t> d_rgb;
+        DevBuf<float> d_mean;
+        d_rgb.alloc(npix * 3);
+        if (out_mean) d_mean.alloc(npix * 3);
+        if (sc->acc.tiled) HIP_CHECK(hipMemset(d_rgb.p, 0, npix * 3));
+        int rc = crt_preview_device(sc, d_rgb.p, out_mean ? d_mean.p : nullptr, nullptr, samples_done);
+        if (rc != CRT_OK) return rc;
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(out_rgb, d_rgb.p, npix * 3, hipMemcpyDeviceToHost));
+        if (out_mean) HIP_CHECK(hipMemcpy(out_mean, d_mean.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
         return CRT_OK;
     } catch (const HipFail& f) {
         return fail_hip(f);

@@ -31,7 +31,7 @@ typedef enum {
     CRT_ERR_INVALID_ARG = -1,
     CRT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at init (reference: src/main.cu:92-105) */
     CRT_ERR_HIP = -3,         /* a HIP call failed; see crt_last_error() */
-    CRT_ERR_UNSUPPORTED = -4, /* valid for the reference but outside this build (e.g. map_Kd textures) */
+    CRT_ERR_UNSUPPORTED = -4, /* valid for the reference but outside this build (e.g. a JPEG map_Kd texture) */
     CRT_ERR_IO = -5,          /* file missing / unreadable */
     CRT_ERR_PARSE = -6,       /* malformed OBJ / MTL / JSON */
     CRT_ERR_OOM = -7
@@ -194,6 +194,15 @@ int crt_render_range(crt_scene* scene, const crt_camera* cam, const crt_params* 
 int crt_render_range_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, uint32_t sample_begin,
                             uint32_t sample_count, void* d_rgb, void* d_mean, void* hip_stream, crt_stats* stats);
 
+/* The displayable frame of a progressive render in flight -- the viewer half of SURVEY 8(f) row 4 (the reference shows nothing
+ * until all spp are done and re-renders from scratch on every click, src/main.cu:368-377).  After a range that ends at
+ * `done` < spp the accumulator holds sum_{k < done} L_k / spp; the preview is tone-map(accumulator * spp / done), written in the
+ * layout of the range calls (row-major, or compact tiles with CRT_FLAG_TILED_OUTPUT).  It only READS the accumulator: the bits
+ * of the final frame do not depend on whether, or how often, previews were taken.  *samples_done (optional) receives `done`.
+ * CRT_ERR_INVALID_ARG when no progressive render is in flight (before the first range, after the one that ends at spp). */
+int crt_preview(crt_scene* scene, uint8_t* out_rgb, float* out_mean, uint32_t* samples_done);
+int crt_preview_device(crt_scene* scene, void* d_rgb, void* d_mean, void* hip_stream, uint32_t* samples_done);
+
 /* ------------------------------------------------------------------------
  * Multi-device rendering in ONE process.  The reference picks device 0 and stops there
  * (config_CUDA, src/main.cu:92-105); a crt_multi holds one device replica of the scene per entry of
@@ -285,6 +294,12 @@ typedef struct {
     float p_rr;
 } crt_task;
 int crt_task_load(const char* config_json_path, crt_task* out);
+
+/* What the reference's texture decoder returns for a map_Kd file -- stbi_load(path, &x, &y, &comp, 0) of Loader.h:58: 8-bit
+ * samples, row 0 = top, the file's own channel count.  Decodes PNG, BMP and TGA (csrc/crt_image.h; pinned against the
+ * reference's vendored stb_image by tests/golden/stb_decode.json); JPEG, GIF, PSD, PIC, PNM and HDR files, which stb_image would
+ * also read, return CRT_ERR_UNSUPPORTED.  out may be NULL (size query); cap = bytes available at out (x * y * comp needed). */
+int crt_image_load(const char* path, int32_t* x, int32_t* y, int32_t* comp, uint8_t* out, uint64_t cap);
 
 /* stb-free PNG writer used by Render::save_frame_buffer's replacement (Render.cuh:489-493) */
 int crt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb);

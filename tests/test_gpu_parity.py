@@ -526,6 +526,44 @@ def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
 
 
 @pytest.mark.parametrize("pipeline", ["2", "4"])
+def test_previews_of_a_progressive_render(renders, pipeline, monkeypatch):
+    """crt_preview (the viewer half of SURVEY 8(f) row 4; the reference shows nothing until all spp are done,
+    src/main.cu:368-377): after `done` samples the preview is the estimate from those samples -- the frame a render with
+    spp = done produces, up to the rounding of (sum L_k / spp) * spp / done -- and taking previews, any number of them,
+    leaves the final frame's bits untouched."""
+    monkeypatch.setenv("CRT_PIPELINE", pipeline)
+    name = "cornell-box"
+    eye, iv, fov = util.camera(name)
+    r = renders[name]
+    r.traversal = crt.TRAVERSAL_FAST
+    w, h, spp = 96, 72, 12
+    r.set_spp(spp)
+    ref = r.run_view(eye, iv, fov, width=w, height=h).copy()
+    ref_mean = r.mean_buffer.copy()
+    with pytest.raises(crt.CrtError):
+        r.preview(width=w, height=h)  # nothing in flight after a complete frame
+    done_at = []
+    out = None
+    for b, c in ((0, 1), (1, 4), (5, 3), (8, 4)):
+        out = r.run_view_range(eye, iv, fov, b, c, width=w, height=h)
+        if b + c < spp:
+            for _ in range(2):  # twice: a preview must not feed back into the accumulator
+                rgb, mean, done = r.preview(want_mean=True, width=w, height=h)
+            assert done == b + c
+            done_at.append((done, rgb.copy(), mean.copy()))
+    assert np.array_equal(out, ref) and np.array_equal(util.bits(r.mean_buffer), util.bits(ref_mean))
+    with pytest.raises(crt.CrtError):
+        r.preview(width=w, height=h)
+    for done, rgb, mean in done_at:  # against a one-shot render of the same samples
+        r.set_spp(done)
+        one = r.run_view(eye, iv, fov, width=w, height=h).astype(np.int32)
+        om = r.mean_buffer
+        assert np.allclose(mean, om, rtol=2e-5, atol=1e-6), done
+        assert np.abs(rgb.astype(np.int32) - one).max() <= 1, done
+    r.set_spp(2)
+
+
+@pytest.mark.parametrize("pipeline", ["2", "4"])
 def test_samples_rendered_in_chunks_equal_one_launch(renders, pipeline, monkeypatch):
     """Frames with more work items than the per-item radiance buffer holds are rendered in chunks of samples (one launch each)
     that accumulate in sample order: forced here with a tiny buffer (7 samples -> 4 launches)."""

@@ -149,6 +149,101 @@ def test_damaged_png_files_are_decoded_or_rejected(tmp_path, kind, w, h):
     assert decoded + rejected == 160 and rejected > 40
 
 
+def _fnv1a64(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xffffffffffffffff
+    return "%016x" % h
+
+
+def test_decoders_match_the_references_own_stb_image():
+    """tests/golden/stb_decode.json = what the reference's vendored stb_image.h returns for the fixture files (x, y, comp and
+    every sample, via oracle/ref_probe/stb_probe.c): the product's decoders (PNG, BMP, TGA) must return exactly that, and so must
+    the PIL-based feed of the oracle for the PNG files (16 -> 8-bit reduction, palette / tRNS expansion, channel counts)."""
+    import json
+    gold = json.load(open(os.path.join(util.ROOT, "tests", "golden", "stb_decode.json")))["files"]
+    assert len(gold) >= 40
+    kinds = set()
+    for name, g in sorted(gold.items()):
+        path = os.path.join(util.ROOT, "tests", "golden", "textures", name)
+        x, y, comp, a = crt.image_load(path)
+        assert (x, y, comp) == (g["x"], g["y"], g["comp"]), name
+        assert _fnv1a64(a) == g["fnv1a64"], name
+        assert list(a.reshape(-1)[:24]) == g["head"], name
+        kinds.add(name.split("_")[0])
+        if name.endswith(".png"):
+            px, py, pc, pa = O.stb_like_decode(path)
+            assert (px, py, pc) == (g["x"], g["y"], g["comp"]) and _fnv1a64(pa) == g["fnv1a64"], name
+    assert kinds == {"png", "bmp", "tga"}
+
+
+@pytest.mark.parametrize("ext,fmt", [("bmp", "BMP"), ("tga", "TGA")])
+def test_bmp_and_tga_textures_feed_the_materials(tmp_path, ext, fmt):
+    """map_Kd pointing at a 24-bit BMP / TGA: per-triangle kd as the oracle computes it from the same samples."""
+    d = str(tmp_path)
+    obj, mtl = _write_scene(d, "rgb", 16, 16)
+    PIL.open(os.path.join(d, "tex.png")).save(os.path.join(d, "tex." + ext), format=fmt)
+    os.remove(os.path.join(d, "tex.png"))
+    m = open(os.path.join(d, "t.mtl")).read().replace("tex.png", "tex." + ext)
+    open(os.path.join(d, "t.mtl"), "w").write(m)
+    x, y, comp, mine = crt.image_load(os.path.join(d, "tex." + ext))
+    px, py, pc, ref = O.stb_like_decode(os.path.join(d, "tex." + ext))
+    assert (x, y, comp) == (px, py, pc) == (16, 16, 3) and np.array_equal(mine, ref)
+    scene = crt.Scene(32, 24)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(2)
+    osc = O.OracleScene([(obj, mtl)], 2)
+    t1, t2 = scene.triangles(), osc.tris()
+    mats = scene.materials()
+    for k in ("kd", "ke", "ns"):
+        assert np.array_equal(util.bits(mats[k][t1["material"]]), util.bits(t2[k])), k
+    assert len(np.unique(mats["kd"][t1["material"]].round(6), axis=0)) > 10
+
+
+def test_formats_outside_this_build_are_named(tmp_path):
+    """stb_image would also read JPEG, GIF, PSD, PIC, PNM and HDR; this build says which format it met and that it is unsupported."""
+    for magic, name in ((b"\xff\xd8\xff\xe0", "JPEG"), (b"GIF89a", "GIF"), (b"8BPS", "PSD"), (b"P6\n2 2\n255\n", "PNM"), (b"#?RADIANCE\n", "Radiance HDR")):
+        p = str(tmp_path / "t.bin")
+        with open(p, "wb") as f:
+            f.write(magic + b"\0" * 64)
+        with pytest.raises(crt.CrtError) as e:
+            crt.image_load(p)
+        assert e.value.status == -4 and name in str(e.value)
+    with pytest.raises(crt.CrtError) as e:
+        crt.image_load(str(tmp_path / "missing.png"))
+    assert e.value.status == -5
+
+
+@pytest.mark.parametrize("name", ["bmp_8_palette.bmp", "bmp_16_565.bmp", "bmp_32_v5_alpha_mask.bmp", "tga_24_rle.tga", "tga_cmap24_rle.tga", "tga_cmap32_idx16.tga"])
+def test_damaged_bmp_and_tga_files_are_decoded_or_rejected(tmp_path, name):
+    """Random damage to valid BMP / TGA files: an image or an error, never an out-of-bounds access."""
+    import random
+    random.seed(11)
+    orig = open(os.path.join(util.ROOT, "tests", "golden", "textures", name), "rb").read()
+    p = str(tmp_path / name)
+    ok = bad = 0
+    for it in range(200):
+        b = bytearray(orig)
+        mode = it % 3
+        if mode == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode == 1:
+            b = b[:random.randrange(1, len(b))]
+        else:
+            i = random.randrange(2, min(len(b) - 4, 60))
+            b[i:i + 4] = random.getrandbits(32).to_bytes(4, "little")
+        with open(p, "wb") as f:
+            f.write(bytes(b))
+        try:
+            x, y, comp, a = crt.image_load(p)
+            assert a.size == x * y * comp and 1 <= comp <= 4
+            ok += 1
+        except crt.CrtError:
+            bad += 1
+    assert ok + bad == 200 and ok > 20
+
+
 @pytest.mark.gpu
 def test_textured_scene_renders_like_oracle(tmp_path):
     obj, mtl = _write_scene(str(tmp_path), "rgb", 16, 16)
