@@ -83,6 +83,14 @@ class MultiInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class BvhBuildInfo(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("levels", C.c_uint32), ("host_ranges", C.c_uint32),
+                ("host_triangles", C.c_uint32), ("device_ms", C.c_float), ("total_ms", C.c_float), ("host_build_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class Task(C.Structure):
     _fields_ = [("n_objs", C.c_uint32), ("obj_path", (C.c_char * 512) * 8), ("mtl_dir", (C.c_char * 512) * 8),
                 ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("eye_pos", C.c_float * 3), ("fov_y", C.c_float),
@@ -101,7 +109,7 @@ EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_coun
            "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
            "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
-           "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_desc", "crt_host_scene_num_objects",
+           "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_set_bvh_device", "crt_host_scene_desc", "crt_host_scene_num_objects",
            "crt_host_scene_object", "crt_inverse_view", "crt_task_load", "crt_image_load", "crt_write_png"]
 
 _lib = None
@@ -147,6 +155,7 @@ def lib():
     L.crt_host_scene_destroy.argtypes = [C.c_void_p]
     L.crt_host_scene_add_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.crt_host_scene_set_bvh.argtypes = [C.c_void_p, C.c_uint32]
+    L.crt_host_scene_set_bvh_device.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(BvhBuildInfo)]
     L.crt_host_scene_desc.argtypes = [C.c_void_p, C.POINTER(SceneDesc)]
     L.crt_host_scene_num_objects.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.crt_host_scene_object.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_int32),

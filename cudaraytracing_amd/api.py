@@ -68,8 +68,16 @@ class Scene:
                    "crt_host_scene_add_obj")
         self._desc = None
 
-    def set_BVH(self, thresh_n):
-        capi.check(capi.lib().crt_host_scene_set_bvh(self._h, thresh_n), "crt_host_scene_set_bvh")
+    def set_BVH(self, thresh_n, device=None):
+        """Scene::set_BVH (Scene.h:50-54).  device=None: the host builder; device=k: the same tree built on GPU k
+        (byte-identical arrays, csrc/crt_bvh_build.hip), self.bvh_build_info says how it went."""
+        if device is None:
+            capi.check(capi.lib().crt_host_scene_set_bvh(self._h, thresh_n), "crt_host_scene_set_bvh")
+            self.bvh_build_info = None
+        else:
+            info = capi.BvhBuildInfo()
+            capi.check(capi.lib().crt_host_scene_set_bvh_device(self._h, thresh_n, device, C.byref(info)), "crt_host_scene_set_bvh_device")
+            self.bvh_build_info = info.as_dict()
         self._desc = None
 
     def desc(self):

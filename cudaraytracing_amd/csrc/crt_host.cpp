@@ -4,11 +4,13 @@
 // dot = p0 + (p1 + p2), normalized = v / sqrt(squaredNorm) with true division,
 // cross as in OrthoMethods.h.  Compiled with -ffp-contract=off.
 #include "crt_host.hpp"
+#include "crt_bvh_build.h"
 #include "crt_image.h"
 
 #include <algorithm>
 #include <array>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -89,6 +91,72 @@ BVH::BVH(unsigned thresh_n, std::vector<Triangle>& triangles) : thresh_n_(thresh
     triangles.swap(sorted);
 }
 
+BVH::BVH(unsigned thresh_n, std::vector<Triangle>& triangles, int device, crt_bvh_build_info* info) : thresh_n_(thresh_n), triangles_(triangles)
+{
+    if (thresh_n == 0) throw Error(CRT_ERR_INVALID_ARG, "bvh_thresh_n must be >= 1 (0 recurses forever in the reference, BVH.h:57-81)");
+    if (triangles.empty()) throw Error(CRT_ERR_INVALID_ARG, "BVH over an empty triangle list");
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t n = triangles.size();
+    std::vector<float> tmin(n * 3), tmax(n * 3), cen(n * 3);
+    bool plain = true; // no -0.0 / NaN / inf: std::min, std::max and the comparator do not depend on scan order
+    for (size_t i = 0; i < n; i++) {
+        const Vec3 lo = triangles[i].get_min(), hi = triangles[i].get_max(), c = triangles[i].get_center();
+        const float v[9] = {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z, c.x, c.y, c.z};
+        for (int k = 0; k < 3; k++) { tmin[i * 3 + k] = v[k]; tmax[i * 3 + k] = v[3 + k]; cen[i * 3 + k] = v[6 + k]; }
+        for (int k = 0; k < 9; k++) plain = plain && std::isfinite(v[k]) && !(v[k] == 0.0f && std::signbit(v[k]));
+    }
+    crt_bvh_build_info bi;
+    std::memset(&bi, 0, sizeof(bi));
+    std::vector<Key> keys(n);
+    auto make_key = [&](size_t pos, uint32_t tri) {
+        keys[pos].c[0] = cen[tri * 3]; keys[pos].c[1] = cen[tri * 3 + 1]; keys[pos].c[2] = cen[tri * 3 + 2];
+        keys[pos].idx = tri;
+    };
+    if (!plain) { // the whole tree on the host
+        for (size_t i = 0; i < n; i++) make_key(i, (uint32_t)i);
+        root_ = build_node(keys, 0, (int)n, 1);
+        bi.n_triangles = (uint32_t)n; bi.n_nodes = (uint32_t)nodes_.size(); bi.host_ranges = 1; bi.host_triangles = (uint32_t)n;
+        bi.levels = max_depth_;
+    } else {
+        std::vector<uint32_t> perm(n);
+        std::vector<crt_bvh_node> flat(2 * n + 1);
+        std::vector<crt_bvh_host_range> ranges;
+        int rc = crt_bvh_build_device((uint32_t)n, tmin.data(), tmax.data(), cen.data(), thresh_n, device, perm.data(), flat.data(), (uint32_t)flat.size(), &ranges, &bi);
+        if (rc != CRT_OK) throw Error(rc, std::string("BVH device build failed: ") + crt_last_error());
+        for (size_t pos = 0; pos < n; pos++) make_key(pos, perm[pos]);
+        nodes_.resize(bi.n_nodes);
+        for (uint32_t i = 0; i < bi.n_nodes; i++) {
+            BVHNode& o = nodes_[i];
+            const crt_bvh_node& f = flat[i];
+            o.lc = f.lc; o.rc = f.rc; o.n = f.n; o.it = f.it;
+            o.AA = mk(f.aa[0], f.aa[1], f.aa[2]); o.BB = mk(f.bb[0], f.bb[1], f.bb[2]);
+        }
+        max_depth_ = bi.levels;
+        const auto h0 = std::chrono::steady_clock::now();
+        for (const crt_bvh_host_range& hr : ranges) { // subtrees with equal sort keys: the reference's own recursion from here on
+            std::vector<BVHNode> whole;
+            whole.swap(nodes_);
+            build_node(keys, (int)hr.l, (int)hr.r, hr.depth);
+            whole.swap(nodes_); // `whole` now holds the subtree in its own post-order numbering
+            for (size_t k = 0; k < whole.size(); k++) {
+                BVHNode nd = whole[k];
+                if (nd.lc >= 0) nd.lc += (int)hr.first_node;
+                if (nd.rc >= 0) nd.rc += (int)hr.first_node;
+                nodes_[hr.first_node + k] = nd;
+            }
+        }
+        bi.host_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        root_ = (int)nodes_.size() - 1;
+    }
+    std::vector<Triangle> sorted;
+    sorted.reserve(n);
+    for (const Key& k : keys) sorted.push_back(triangles[k.idx]);
+    triangles.swap(sorted);
+    bi.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!plain) bi.host_build_ms = bi.total_ms;
+    if (info) *info = bi;
+}
+
 int BVH::build_node(std::vector<Key>& keys, int l, int r, unsigned depth)
 {
     if (l >= r) return -1;
@@ -145,6 +213,14 @@ void Scene::set_BVH(unsigned thresh_n)
     delete bvh_;
     bvh_ = nullptr;
     bvh_ = new BVH(thresh_n, triangles_); // Scene.h:50-54
+    flat_valid_ = false;
+}
+void Scene::set_BVH_device(unsigned thresh_n, int device, crt_bvh_build_info* info)
+{
+    if (triangles_.empty()) throw Error(CRT_ERR_INVALID_ARG, "Scene::set_BVH on an empty scene");
+    delete bvh_;
+    bvh_ = nullptr;
+    bvh_ = new BVH(thresh_n, triangles_, device, info);
     flat_valid_ = false;
 }
 void Scene::free()
@@ -666,6 +742,11 @@ int crt_host_scene_set_bvh(crt_host_scene* s, uint32_t thresh_n)
 {
     if (!s) { g_last_error = "crt_host_scene_set_bvh: null scene"; return CRT_ERR_INVALID_ARG; }
     CRT_HOST_TRY(s->scene.set_BVH(thresh_n));
+}
+int crt_host_scene_set_bvh_device(crt_host_scene* s, uint32_t thresh_n, int device, crt_bvh_build_info* info)
+{
+    if (!s) { g_last_error = "crt_host_scene_set_bvh_device: null scene"; return CRT_ERR_INVALID_ARG; }
+    CRT_HOST_TRY(s->scene.set_BVH_device(thresh_n, device, info));
 }
 int crt_host_scene_desc(const crt_host_scene* s, crt_scene_desc* out)
 {

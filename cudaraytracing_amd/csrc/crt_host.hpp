@@ -102,6 +102,9 @@ struct BVHNode {
 class BVH {
 public:
     BVH(unsigned thresh_n, std::vector<Triangle>& triangles);
+    // the same tree built on GPU `device` (csrc/crt_bvh_build.hip), byte-identical node and triangle arrays; ranges with equal
+    // sort keys are finished by build_node on the host
+    BVH(unsigned thresh_n, std::vector<Triangle>& triangles, int device, crt_bvh_build_info* info);
     int get_root_index() const { return root_; }
     size_t get_nodes_size() const { return nodes_.size(); }
     const std::vector<BVHNode>& get_nodes() const { return nodes_; }
@@ -129,6 +132,7 @@ public:
     void add_light_obj(Object& obj);
     void add_normal_obj(Object& obj);
     void set_BVH(unsigned thresh_n);
+    void set_BVH_device(unsigned thresh_n, int device, crt_bvh_build_info* info = nullptr);
     void free();
     unsigned get_height() const { return height_; }
     unsigned get_width() const { return width_; }
