@@ -76,6 +76,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the veach-mis 800x600 spp=1024 sub-record")
     ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--frames-in-flight", type=int, default=1, choices=[1, 2],
+                    help="1 (default): one frame at a time, ms_per_step is a frame's latency.  2: frames are pipelined over two device "
+                         "replicas of the scene and two streams of different priority, so that the end of one launch (every wave running "
+                         "its pool of paths dry) overlaps the start of the next: measured 0.5 %% / 1 %% / 2.5 %% / 4.9 %% on a rank's "
+                         "share of C2 at 1 / 2 / 4 / 8 ranks (tools/pipeline_probe.py), but k_accumulate of frame i then waits for "
+                         "kernel i+1 (no free VGPRs) and a frame's latency doubles -- an option, not the reported number")
     ap.add_argument("--save-png", default=None)
     return ap.parse_args()
 
@@ -195,6 +201,12 @@ def main_rank(args):
     render = crt.Render(scene, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
     render.seed = args.seed
     render.traversal = trav
+    pipelined = args.frames_in_flight > 1 and not multi
+    render2 = None
+    if pipelined:
+        render2 = crt.Render(scene, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
+        render2.seed = args.seed
+        render2.traversal = trav
 
     def step():
         if multi:
@@ -204,23 +216,51 @@ def main_rank(args):
             return None, st
         return render_sharded(render, eye, inv_view, fov, args.width, args.height, rank, world, device)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
     kernel_ms, logic_ms, kernel_launches = [], [], []
     rays_local = 0
     untraced_local = 0
     img = None
-    for _ in range(args.steps):
+    frame_latency_ms = None
+    if pipelined:
+        from cudaraytracing_amd.distributed import FramePipeline
+        # one unpipelined frame with statistics: ray counts (identical for every frame of a fixed seed) and a frame's own latency
+        barrier()
+        c0 = time.perf_counter()
         img, st = step()
-        kernel_ms.append(st["kernel_ms"])
-        logic_ms.append(st["logic_ms"])
+        barrier()
+        frame_latency_ms = (time.perf_counter() - c0) * 1e3
+        rays_local, untraced_local = st["rays"], st.get("rays_untraced", 0)
         kernel_launches.append(st["kernel_launches"])
-        rays_local = st["rays"]
-        untraced_local = st.get("rays_untraced", 0)
-    barrier()
-    elapsed = time.perf_counter() - t0
+        logic_ms.append(st["logic_ms"])
+        pipe = FramePipeline([render, render2], eye, inv_view, fov, args.width, args.height, rank, world, device)
+        for _ in range(max(args.warmup, 2)):   # both handles warm (pool and radiance buffers allocated)
+            pipe.submit()
+        pipe.drain()
+        pipe.done.clear(); pipe.kernel_ms.clear()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.submit()
+        pipe.drain()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        assert len(pipe.done) == args.steps
+        img = pipe.done[-1]
+        kernel_ms = list(pipe.kernel_ms)
+    else:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img, st = step()
+            kernel_ms.append(st["kernel_ms"])
+            logic_ms.append(st["logic_ms"])
+            kernel_launches.append(st["kernel_launches"])
+            rays_local = st["rays"]
+            untraced_local = st.get("rays_untraced", 0)
+        barrier()
+        elapsed = time.perf_counter() - t0
     red_dev = torch.device("cpu") if one_device else device
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     r = torch.tensor([float(rays_local)], dtype=torch.float64, device=red_dev)
@@ -404,6 +444,8 @@ def main_rank(args):
                                            "`all_rays_traced` times the same frame with every one of them traced"
                                            % (100.0 * untraced_local / max(1, rays_local), "" if multi else " on rank 0")},
             "frames_per_sec": round(1e3 / ms_per_step, 4),
+            "frames_in_flight": 2 if pipelined else 1,
+            "frame_latency_ms": round(frame_latency_ms, 3) if frame_latency_ms is not None else round(ms_per_step, 3),
             "rays_per_frame": int(rays_frame),
             "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
                                "equal to the oracle's count",
@@ -429,6 +471,8 @@ def main_rank(args):
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     render.free()
+    if render2 is not None:
+        render2.free()
     if mr is not None:
         mr.free()
     if world > 1:

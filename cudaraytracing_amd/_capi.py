@@ -106,7 +106,7 @@ LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
-           "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
+           "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
            "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_set_bvh_device", "crt_host_scene_desc", "crt_host_scene_num_objects",
@@ -140,6 +140,7 @@ def lib():
                                    C.POINTER(Stats)]
     L.crt_render_range_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.crt_last_launch_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
     L.crt_preview.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.crt_preview_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.crt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]

@@ -222,6 +222,13 @@ class Render:
             self.frame_buffer, self.mean_buffer = rgb, mean
         return rgb
 
+    def last_launch_ms(self):
+        """(device ms, launches) of the render kernel of the last frame submitted on this handle (crt_last_launch_ms); the frame's
+        stream must have been synchronized."""
+        ms, n = C.c_float(), C.c_uint32()
+        capi.check(capi.lib().crt_last_launch_ms(self._h, C.byref(ms), C.byref(n)), "crt_last_launch_ms")
+        return float(ms.value), int(n.value)
+
     def preview(self, want_mean=False, width=None, height=None):
         """Displayable frame of the progressive render in flight (crt_preview): returns (rgb (H, W, 3), mean or None, samples done).
         Reads the accumulator only -- the final frame does not depend on previews."""

@@ -941,14 +941,25 @@ static_assert(POOL3_QCAP >= POOL3_P, "a ring must hold every ray of the pool");
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef CRT_INV_LDS
+#define CRT_INV_LDS 1 /* 1: 1/direction is part of the ray record (64 B per ray); 0: the inner step recomputes it from the direction (52 B per ray) */
+#endif
+#ifndef CRT_WAVES
+#define CRT_WAVES 4   /* waves per SIMD the kernel is compiled for; the LDS footprint of a pool must allow it (160 KiB per CU) */
+#endif
 struct Pool3Lds {
     float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
     float4 B[POOL3_P];           // direction.xyz, bits(best triangle, -1 = none)
+#if CRT_INV_LDS
     float4 C[POOL3_P];           // 1/direction.xyz (Ray.cuh:14), bits(current node ref)
+#else
+    int node[POOL3_P];           // current node ref
+#endif
     int stk[POOL_LV][POOL3_P];   // traversal stack (node refs); deeper levels spill to global memory
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N][POOL3_QCAP];
 };
+static_assert(sizeof(Pool3Lds) * 4 * CRT_WAVES <= 160 * 1024, "the pool does not fit CRT_WAVES waves per SIMD into 160 KiB of LDS");
 
 struct MParams3 {
     MParams M;
@@ -1022,6 +1033,19 @@ __device__ __forceinline__ uint32_t route_done(uint32_t flags)
     return (flags & RF_SHADOW) ? ((flags & RF_LAST) ? PH3_LB : PH3_LA) : ((flags & (RF_PROBE | RF_HASHIT)) ? PH3_LA : PH3_LC);
 }
 
+// 1 / d per component (Ray.cuh:14), bit for bit the IEEE quotient: the short reciprocal where it is proven equal (rcp_ieee),
+// the division itself for the other lanes behind a wave-uniform branch.
+__device__ __forceinline__ F3 inv3_exact(const F3 d)
+{
+    F3 inv = f3(rcp_short(d.x), rcp_short(d.y), rcp_short(d.z));
+    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z));
+    const bool ok = rcp_short_ok3(d.x, d.y, d.z);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        if (!ok) inv = f3(1 / d.x, 1 / d.y, 1 / d.z);
+    }
+    return inv;
+}
+
 // Writes the new ray into the pool record `id` and returns its first phase.
 template <int MODE, bool QUERY = false>
 __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
@@ -1029,14 +1053,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     cnt.rays++;
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
     cnt.probe += (nr.flags & RF_PROBE) ? 1u : 0u;
-    F3 inv = f3(rcp_short(nr.d.x), rcp_short(nr.d.y), rcp_short(nr.d.z)); // 1 / d (Ray.cuh:14), see rcp_ieee
-    {
-        asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z));
-        const bool ok = rcp_short_ok3(nr.d.x, nr.d.y, nr.d.z);
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
-            if (!ok) inv = f3(1 / nr.d.x, 1 / nr.d.y, 1 / nr.d.z);
-        }
-    }
+    const F3 inv = inv3_exact(nr.d); // 1 / d (Ray.cuh:14)
     uint32_t flags = nr.flags & ~RF_SKIP;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
@@ -1055,7 +1072,11 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     }
     S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, T);
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
+#if CRT_INV_LDS
     S.C[id] = make_float4(inv.x, inv.y, inv.z, __int_as_float(ref));
+#else
+    S.node[id] = ref;
+#endif
     S.D[id] = flags;
     if (answered) return route_done<QUERY>(flags);
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
@@ -1449,10 +1470,20 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
 // maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
-                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu)
+                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu
+#ifdef CRT_STAMPS
+                                            , unsigned long long* dg_sec, unsigned long long& dg_t0
+#endif
+                                            )
 {
+#ifdef CRT_STAMPS
+#define CRT_SEC4(i, dep) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(dep) : "memory"); unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_sec[i] += t_now - dg_t0; dg_t0 = t_now; }
+#else
+#define CRT_SEC4(i, dep)
+#endif
     const float4* nd = (const float4*)((const char*)sc.nodes4 + (uint32_t)ref * 128u); // 32-bit byte offset: scalar base + vector offset addressing
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
+    CRT_SEC4(2, a0.x + a1.x + a2.x + b0.x + b1.x + b2.x + rf.x)
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
     slab_pair_pruned(a0, a1, a2, o, inv, bound, t0, t1);
@@ -1486,6 +1517,8 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     }
     sp = l1 + (c1 ? 1 : 0);
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    CRT_SEC4(3, sp + r0)
+#undef CRT_SEC4
     if (c0) { ref = r0; return false; }
     return stack_pop(S, M, id, g, sp, ref);
 }
@@ -1526,7 +1559,7 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
 template <int MODE, bool STATS, bool ALL = false, bool QUERY = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mega3(const MParams3 M3)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, CRT_WAVES))) void k_mega3(const MParams3 M3)
 {
     __shared__ Pool3Lds S;
     const MParams& M = M3.M;
@@ -1588,6 +1621,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
         }                                                                                                                  \
     }
+// the same for ONE ring and an explicit lane predicate
+#define PUSH1(p, cond)                                                                                                     \
+    {                                                                                                                      \
+        const bool mine_ = (cond);                                                                                         \
+        const unsigned long long m_ = __ballot(mine_);                                                                     \
+        if (m_) {                                                                                                          \
+            const int rank_ = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
+            if (mine_) S.ring[p][ring_wrap((uint32_t)(qt[p] + rank_))] = (uint8_t)id;                                      \
+            const int add_ = (int)__popcll(m_);                                                                            \
+            qn[p] += add_;                                                                                                 \
+            qt[p] += add_;                                                                                                 \
+            if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
+        }                                                                                                                  \
+    }
+// after a traversal step: a ray goes on to an inner node or a leaf, or it is finished -- only then (one wave-uniform test
+// for the three logic rings together) is its route worked out from the flag bits of its record
+#ifdef CRT_PUSH_SPLIT /* measured on C2: 118.6 ms against 116.5 ms for the generic five-ring push -- kept for reference only */
+#define PUSH_TRAV()                                                                                                        \
+    PUSH1(PH3_INNER, on && !t_done && t_ref >= 0)                                                                          \
+    PUSH1(PH3_LEAF, on && !t_done && t_ref < 0)                                                                            \
+    if (__ballot(on && t_done)) {                                                                                          \
+        const uint32_t r_ = route_done<QUERY>(t_flags);                                                                    \
+        PUSH1(PH3_LA, on && t_done && r_ == PH3_LA)                                                                        \
+        PUSH1(PH3_LB, on && t_done && r_ == PH3_LB)                                                                        \
+        PUSH1(PH3_LC, on && t_done && r_ == PH3_LC)                                                                        \
+    }
+#else
+#define PUSH_TRAV() { if (on) nph = t_done ? route_done<QUERY>(t_flags) : (t_ref >= 0 ? PH3_INNER : PH3_LEAF); PUSH3() }
+#endif
 // takes the (up to) 64 oldest rays of ring p
 #define POP3(p)                                                                                                            \
     const int take = min(64, qn[p]);                                                                                       \
@@ -1645,12 +1707,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             dg_lanes[PH3_INNER] += (unsigned)take;
 #endif
             CRT_SEC3(0, id)
+            bool t_done = false;
+            int t_ref = 0;
+            uint32_t t_flags = 0;
             if (on) {
+#if CRT_INV_LDS
                 const float4 qa = S.A[id], qc = S.C[id];
                 const uint32_t qd = S.D[id];
                 CRT_SEC3(1, qa.x + qc.x + __uint_as_float(qd))
                 int ref = __float_as_int(qc.w);
                 const F3 o = f3(qa.x, qa.y, qa.z), inv = f3(qc.x, qc.y, qc.z);
+#else
+                const float4 qa = S.A[id], qbd = S.B[id];
+                const uint32_t qd = S.D[id];
+                int ref = S.node[id];
+                CRT_SEC3(1, qa.x + qbd.x + __uint_as_float(qd))
+                const F3 o = f3(qa.x, qa.y, qa.z), inv = inv3_exact(f3(qbd.x, qbd.y, qbd.z));
+#endif
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
                 const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w) : FLT_MAX;
@@ -1660,7 +1733,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     done = inner2_step<1, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
+#ifdef CRT_STAMPS
+                    if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu, dg_sec, dg_t0);
+#else
                     if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
+#endif
                     if (__builtin_amdgcn_ballot_w64(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
                         if (ex) {
                             const float4 qb = S.B[id];
@@ -1669,12 +1746,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
                 }
                 CRT_SEC3(4, ref + sp)
+#if CRT_INV_LDS
                 S.C[id].w = __int_as_float(ref);
+#else
+                S.node[id] = ref;
+#endif
                 S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
                 if (STATS && done && (qd & RF_HASHIT)) tc.hits++; // (an any-hit ray that records a hit ends in the leaf step)
-                nph = done ? route_done<QUERY>(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                t_done = done; t_ref = ref; t_flags = qd;
             }
-            PUSH3()
+            PUSH_TRAV()
             CRT_SEC3(5, nph)
         } else if (act == PH3_LEAF) {
             // ---- leaf step: the record's two triangles in one packed computation ----
@@ -1682,9 +1763,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #ifdef CRT_STAMPS
             dg_lanes[PH3_LEAF] += (unsigned)take;
 #endif
+            bool t_done = false;
+            int t_ref = 0;
+            uint32_t t_flags = 0;
             if (on) {
                 const float4 qa = S.A[id], qb = S.B[id];
+#if CRT_INV_LDS
                 int ref = __float_as_int(S.C[id].w);
+#else
+                int ref = S.node[id];
+#endif
                 uint32_t qd = S.D[id];
                 const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
                 float T = qa.w;
@@ -1727,12 +1815,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
+#if CRT_INV_LDS
                 S.C[id].w = __int_as_float(ref);
+#else
+                S.node[id] = ref;
+#endif
                 S.D[id] = qd;
                 if (STATS && done && tri >= 0) tc.hits++;
-                nph = done ? route_done<QUERY>(qd) : (ref >= 0 ? PH3_INNER : PH3_LEAF);
+                t_done = done; t_ref = ref; t_flags = qd;
             }
-            PUSH3()
+            PUSH_TRAV()
         } else if (act == PH3_LA) {
             POP3(PH3_LA)
 #ifdef CRT_STAMPS
@@ -1773,6 +1865,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         CRT_STAMP3(act)
     }
 #undef PUSH3
+#undef PUSH1
+#undef PUSH_TRAV
 #undef POP3
 #undef LOGIC_PARAMS
 
@@ -2026,6 +2120,8 @@ struct crt_scene {
     DevBuf<int2> spill[2];                    // traversal stack overflow, one per pool half
     hipStream_t aux_stream = nullptr;         // second pool half runs here so that k_logic overlaps k_trace
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr; // around the k_mega3 launches of the last frame, recorded without synchronizing (crt_last_launch_ms)
+    uint32_t last_launches = 0;
     int n_cus = 0;
     unsigned long long* h_counters = nullptr; // pinned copy of counters
     DevScene dev{};
@@ -2037,6 +2133,8 @@ struct crt_scene {
     ~crt_scene()
     {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (ev_k0) (void)hipEventDestroy(ev_k0);
+        if (ev_k1) (void)hipEventDestroy(ev_k1);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (aux_stream) (void)hipStreamDestroy(aux_stream);
@@ -2386,6 +2484,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 M.P = P;
                 HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
+                if (s0 == s_begin) HIP_CHECK(hipEventRecord(sc->ev_k0, st));
                 {
                     MParams3 M3;
                     M3.M = M;
@@ -2402,6 +2501,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
                 }
                 HIP_CHECK(hipGetLastError());
+                if (s0 + ns >= s_end) HIP_CHECK(hipEventRecord(sc->ev_k1, st));
                 if (timing) {
                     HIP_CHECK(hipEventRecord(e2, st));
                     HIP_CHECK(hipStreamSynchronize(st));
@@ -2410,6 +2510,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     kernel_ms += ms;
                 }
                 launches++;
+                sc->last_launches = launches;
                 A.chunk_samples = ns;
                 A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
                 hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
@@ -2796,6 +2897,8 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         HIP_CHECK(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&sc->ev_fork, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&sc->ev_join, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreate(&sc->ev_k0));
+        HIP_CHECK(hipEventCreate(&sc->ev_k1));
         {
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -2891,6 +2994,16 @@ int crt_render_range(crt_scene* sc, const crt_camera* cam, const crt_params* prm
     } catch (const HipFail& f) {
         return fail_hip(f);
     }
+}
+
+int crt_last_launch_ms(crt_scene* sc, float* ms, uint32_t* launches)
+{
+    if (!sc || !ms) return fail(CRT_ERR_INVALID_ARG, "crt_last_launch_ms: null argument");
+    if (sc->last_launches == 0) return fail(CRT_ERR_INVALID_ARG, "crt_last_launch_ms: no frame has been rendered by the megakernel on this handle");
+    hipError_t e = hipEventElapsedTime(ms, sc->ev_k0, sc->ev_k1);
+    if (e != hipSuccess) return fail(CRT_ERR_HIP, std::string("crt_last_launch_ms: hipEventElapsedTime: ") + hipGetErrorString(e) + " (synchronize the stream first)");
+    if (launches) *launches = sc->last_launches;
+    return CRT_OK;
 }
 
 int crt_preview_device(crt_scene* sc, void* d_rgb, void* d_mean, void* stream, uint32_t* samples_done)

@@ -102,3 +102,55 @@ def render_sharded(render, eye, inv_view, fov_y, width, height, rank, world, dev
     stats = render.run_view_device(eye, inv_view, fov_y, local.data_ptr(), None, stream, rank=rank, world=world,
                                    tiled=True, want_stats=want_stats, width=width, height=height)
     return gather_image(local, width, height, world, group), stats
+
+
+class FramePipeline:
+    """Two frames in flight per rank.  Every launch of the persistent render kernel ends with its waves running their private
+    path pools dry (about 2 ms, DESIGN.md "Multi-GPU"): with one frame at a time that tail is idle GPU, 1.7 % of a C2 frame on
+    one GPU and 12 % of a rank's share on eight.  The pipeline alternates two device replicas of the scene (two crt_scene handles:
+    path pools, per-path radiance and accumulators are per handle) on two HIP streams, so the workgroups of frame i+1 are
+    dispatched into the compute units as the waves of frame i retire; the tile gather of a frame is enqueued on the frame's
+    own stream behind its kernels.  Frames complete in submission order; nothing synchronizes the host until `drain()` or until
+    a handle is reused (by then its previous frame has long finished).
+
+    submit() returns nothing; finished frames are collected in `self.done` as (image tensor, kernel ms) in submission order."""
+
+    def __init__(self, renders, eye, inv_view, fov_y, width, height, rank, world, device, group=None, depth=2):
+        import torch
+        self.renders = list(renders)[:max(1, depth)]
+        self.args = (eye, inv_view, fov_y, width, height, rank, world, device, group)
+        # HIP multiplexes streams onto a few hardware queues and kernels of one queue run back to back: two streams of the SAME priority
+        # landed on one queue here (rocprofv3 kernel trace: Queue_Id equal, no overlap).  Streams of different priorities live on
+        # different queues, so the two frames in flight alternate between a normal and a high-priority stream.
+        self.streams = [torch.cuda.Stream(device=device, priority=(0 if k % 2 == 0 else -1)) for k in range(len(self.renders))]
+        self.pending = [None] * len(self.renders)   # per handle: image tensor of the frame in flight
+        self.next = 0
+        self.done = []
+        self.kernel_ms = []
+
+    def _retire(self, h):
+        if self.pending[h] is not None:
+            self.streams[h].synchronize()
+            ms, _ = self.renders[h].last_launch_ms()
+            self.kernel_ms.append(ms)
+            self.done.append(self.pending[h])
+            self.pending[h] = None
+
+    def submit(self):
+        import torch
+        from .api import shard_slots
+        eye, inv_view, fov_y, width, height, rank, world, device, group = self.args
+        h = self.next
+        self.next = (self.next + 1) % len(self.renders)
+        self._retire(h)   # (the frame submitted two submissions ago: finished unless the pipeline is starved)
+        s = self.streams[h]
+        with torch.cuda.stream(s):
+            slots = shard_slots(width, height, rank, world)
+            local = torch.empty((slots, 3), dtype=torch.uint8, device=device)
+            self.renders[h].run_view_device(eye, inv_view, fov_y, local.data_ptr(), None, s.cuda_stream, rank=rank, world=world, tiled=True,
+                                            want_stats=False, width=width, height=height)
+            self.pending[h] = gather_image(local, width, height, world, group)
+
+    def drain(self):
+        for k in range(len(self.renders)):
+            self._retire((self.next + k) % len(self.renders))

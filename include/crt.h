@@ -183,6 +183,11 @@ int crt_render(crt_scene* scene, const crt_camera* cam, const crt_params* params
 int crt_render_device(crt_scene* scene, const crt_camera* cam, const crt_params* params, void* d_rgb,
                       void* d_mean, void* hip_stream, crt_stats* stats);
 
+/* Device time of the render kernel launches of the LAST frame submitted on the handle (first launch's start to last launch's end, HIP
+ * events recorded on the frame's stream without synchronizing): lets a caller that pipelines frames with crt_render_device(stats = NULL)
+ * read every frame's kernel time afterwards.  The frame's stream must have been synchronized (CRT_ERR_HIP otherwise). */
+int crt_last_launch_ms(crt_scene* scene, float* ms, uint32_t* launches);
+
 /* Progressive rendering (the reference re-renders all spp on every click, src/main.cu:368-377):
  * renders samples [sample_begin, sample_begin + sample_count) of params->spp into the accumulator the scene handle
  * owns (temp_color += L_k / spp, in sample order as Render.cuh:348).  Ranges must be submitted in ascending order
