@@ -85,7 +85,7 @@ class MultiInfo(C.Structure):
 
 class BvhBuildInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("levels", C.c_uint32), ("host_ranges", C.c_uint32),
-                ("host_triangles", C.c_uint32), ("device_ms", C.c_float), ("total_ms", C.c_float), ("host_build_ms", C.c_float)]
+                ("host_triangles", C.c_uint32), ("host_sorts", C.c_uint32), ("host_sort_elements", C.c_uint64), ("device_ms", C.c_float), ("total_ms", C.c_float), ("host_build_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

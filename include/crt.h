@@ -277,15 +277,19 @@ int crt_host_scene_destroy(crt_host_scene* scene); /* Scene::free */
 int crt_host_scene_add_obj(crt_host_scene* scene, const char* obj_path, const char* mtl_dir);
 /* Scene::set_BVH(thresh_n) (Scene.h:50-54 -> BVH.h:30-84) */
 int crt_host_scene_set_bvh(crt_host_scene* scene, uint32_t thresh_n);
-/* The same BVH built on the GPU (csrc/crt_bvh_build.hip): level-synchronous median split, one radix sort of
- * the whole triangle order per level.  Node and triangle arrays are BYTE-IDENTICAL to crt_host_scene_set_bvh's: ranges whose
- * sort keys are pairwise different have one sorted order whatever the algorithm; a range with two equal centroid coordinates --
- * where std::sort's order is its own -- is handed, with its subtree, to the host builder (info->host_ranges / host_triangles say
- * how much that was); scenes with -0.0 or non-finite coordinates are built on the host entirely (info->host_triangles = all). */
+/* The same BVH built on the GPU (csrc/crt_bvh_build.hip): level-synchronous median split; per level the
+ * device replays the quicksort phase of libstdc++'s std::sort on every range (equal centroid coordinates are the norm on real
+ * meshes, and an unstable sort's order of equal keys is its own) and finishes with one stable radix sort of the whole triangle
+ * order.  Node and triangle arrays are BYTE-IDENTICAL to crt_host_scene_set_bvh's.  A range whose quicksort phase hits std::sort's
+ * depth limit is sorted by the host between two levels (info->host_sorts); scenes with -0.0 or non-finite coordinates are built on
+ * the host entirely (info->host_triangles = all). */
 typedef struct {
     uint32_t n_triangles, n_nodes, levels;
-    uint32_t host_ranges;      /* subtrees finished by the host builder (ties among the sort keys) */
+    uint32_t host_ranges;      /* subtrees finished by the host builder (none unless a range's extents are NaN) */
     uint32_t host_triangles;   /* triangles in them */
+    uint32_t host_sorts;       /* single range sorts done by the host's std::sort between two levels: ranges whose quicksort phase ran into
+                                  std::sort's depth limit (heapsort), e.g. already-sorted keys full of ties */
+    uint64_t host_sort_elements;
     float device_ms;           /* HIP events around the level loop */
     float total_ms;            /* host clock: uploads, level loop, downloads, host subtrees */
     float host_build_ms;       /* host clock: the host builder's part (host ranges, or everything on a fallback) */
