@@ -13,7 +13,8 @@
 
 A "step" is one complete frame: every rank path-traces its interleaved 8x8 pixel tiles with the HIP kernels of
 libcrt.so, the compact RGB8 tile buffers are all-gathered over RCCL and de-interleaved into the final image.
-The total work is fixed as N grows ("strong" scaling).
+The total work is fixed as N grows ("strong" scaling).  One frame at a time (ms_per_step is a frame's latency);
+--frames-in-flight 2 overlaps consecutive frames (an option, see its help text).
 
 A ray is one closest-hit query of the reference (DeviceBVH::intersect): primary, bounce, shadow and specular-probe
 rays; the count is deterministic given (scene, config, seed) and comes from the kernel's counters.
