@@ -63,16 +63,38 @@ def _stale(target, deps, check_flags=False):
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
 
 
+class _BuildLock:
+    """The N ranks of a multi-GPU job load the library at the same moment: the staleness check and a rebuild are serialised
+    across processes (first one builds into a temporary file and renames it, the others then find a fresh library)."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(LIBDIR, exist_ok=True)
+        self.f = open(os.path.join(LIBDIR, ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
 def build_lib(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _stale(LIB, LIB_DEPS, check_flags=True):
         return LIB
-    cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-ldl", "-lpthread", "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    with open(FLAGS_FILE, "w") as f:
-        f.write(flags_string() + "\n")
+    with _BuildLock():
+        if not force and not _stale(LIB, LIB_DEPS, check_flags=True):  # another process has built it meanwhile
+            return LIB
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-ldl", "-lpthread", "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+        with open(FLAGS_FILE, "w") as f:
+            f.write(flags_string() + "\n")
     return LIB
 
 
