@@ -91,6 +91,14 @@ class BvhBuildInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class AccelInfo(C.Structure):
+    _fields_ = [("n_leaves", C.c_uint32), ("n_nodes2", C.c_uint32), ("n_nodes4", C.c_uint32), ("depth2", C.c_uint32), ("depth4", C.c_uint32),
+                ("sah_on_device", C.c_uint32), ("index_splits", C.c_uint32), ("sah_ms", C.c_float), ("sah_device_ms", C.c_float)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class Task(C.Structure):
     _fields_ = [("n_objs", C.c_uint32), ("obj_path", (C.c_char * 512) * 8), ("mtl_dir", (C.c_char * 512) * 8),
                 ("lookat", C.c_float * 3), ("up", C.c_float * 3), ("eye_pos", C.c_float * 3), ("fov_y", C.c_float),
@@ -106,7 +114,7 @@ LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
-           "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
+           "crt_scene_accel_info", "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
            "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_set_bvh_device", "crt_host_scene_desc", "crt_host_scene_num_objects",
@@ -131,6 +139,7 @@ def lib():
     L.crt_last_error.restype = C.c_char_p
     L.crt_device_count.argtypes = [C.POINTER(C.c_int)]
     L.crt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+    L.crt_scene_accel_info.argtypes = [C.c_void_p, C.POINTER(AccelInfo)]
     L.crt_scene_destroy.argtypes = [C.c_void_p]
     L.crt_shard_slots.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
     L.crt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]

@@ -167,6 +167,12 @@ class Render:
         self.mean_buffer = None
         self.stats = None
 
+    def accel_info(self):
+        """How the acceleration trees of the FAST traversal were built (crt_scene_accel_info)."""
+        a = capi.AccelInfo()
+        capi.check(capi.lib().crt_scene_accel_info(self._h, C.byref(a)), "crt_scene_accel_info")
+        return a.as_dict()
+
     def set_spp(self, spp):
         self.spp = int(spp)
 
@@ -341,6 +347,9 @@ class MultiRender(Render):
 
     def preview(self, *a, **k):
         raise NotImplementedError("previews are a single-device interface (crt_preview)")
+
+    def accel_info(self):
+        raise NotImplementedError("crt_scene_accel_info is a single-device interface")
 
     def run_view_device(self, *a, **k):
         raise NotImplementedError("MultiRender owns its device buffers (crt_multi_frame_device)")

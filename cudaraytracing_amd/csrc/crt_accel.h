@@ -54,9 +54,10 @@ struct Node {          // inner node: two children with their boxes
 
 // Builds the tree; nodes are returned in breadth-first order (root = 0).  Returns the depth
 // (a tree that is a single leaf has depth 1 and no inner nodes; root_ref tells which).
-inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t& root_ref)
+inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t& root_ref, uint32_t* index_splits = nullptr)
 {
     nodes.clear();
+    if (index_splits) *index_splits = 0;
     const int n = (int)prims.size();
     if (n == 1) { root_ref = prims[0].ref; return 1; }
     const int NB = 32;
@@ -117,6 +118,7 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
         int mid;
         if (best_axis < 0) {
             mid = b + cnt / 2; // all centroids coincide: split by index
+            if (index_splits) (*index_splits)++;
         } else {
             const int a = best_axis;
             const float scale = (float)NB / (chi[a] - clo[a]);
@@ -169,6 +171,10 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
     root_ref = 0;
     return max_depth;
 }
+
+// The same tree built on the current HIP device (crt_accel_build.hip): node for node the tree of build_sah, except where a range is
+// split "by index" (coinciding centroids).  Returns the depth, or -1 if the device build could not run (use build_sah then).
+int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t& root_ref, float* device_ms, uint32_t* index_splits = nullptr);
 
 } // namespace crtaccel
 #endif

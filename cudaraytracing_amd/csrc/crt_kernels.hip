@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -2127,6 +2128,7 @@ struct crt_scene {
     DevScene dev{};
     int stack_cap = 0;
     uint32_t n_tris = 0;
+    crt_accel_info accel{};
     // progressive render in flight: what the accumulator holds (crt_preview)
     struct { uint32_t samples = 0, spp = 0, width = 0, height = 0, rank = 0, world = 1, tiled = 0; } acc;
     std::vector<hipEvent_t> ev;
@@ -2161,7 +2163,11 @@ float as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 //   [A, A + R)  the reference's own topology (post-order BVH re-laid breadth-first), used by
 //               CRT_TRAVERSAL_REFERENCE and by FAST rays whose inv_dir is not finite.
 // Returns the larger tree depth (root = 1).
-int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector<int32_t>& leaf_count, int32_t& root_fast, int32_t& root_exact)
+struct AccelInfo {
+    uint32_t n_leaves = 0, n_nodes2 = 0, on_device = 0, index_splits = 0;
+    float sah_ms = 0.0f, sah_device_ms = 0.0f;
+};
+int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector<int32_t>& leaf_count, int32_t& root_fast, int32_t& root_exact, AccelInfo* ai = nullptr)
 {
     auto is_leaf = [&](int32_t i) { return d.nodes[i].lc < 0 && d.nodes[i].rc < 0; };
     auto leaf_ref = [&](int32_t i) -> int32_t {
@@ -2185,7 +2191,22 @@ int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector
     }
     std::vector<crtaccel::Node> acc;
     int32_t acc_root = 0;
-    int depth_fast = crtaccel::build_sah(prims, acc, acc_root);
+    // the SAH tree over the reference leaves: on the device (crt_accel_build.hip; CRT_SAH_HOST=1 forces the host builder, which is
+    // also the fallback); the 4-wide collapse below stays on the host (linear, a few hundred microseconds)
+    const auto sah_t0 = std::chrono::steady_clock::now();
+    int depth_fast = -1;
+    float dev_ms = 0.0f;
+    const bool want_device = !(std::getenv("CRT_SAH_HOST") && std::getenv("CRT_SAH_HOST")[0] == '1');
+    uint32_t index_splits = 0;
+    if (want_device) depth_fast = crtaccel::build_sah_device(prims, acc, acc_root, &dev_ms, &index_splits);
+    const bool on_device = depth_fast >= 0;
+    if (!on_device) depth_fast = crtaccel::build_sah(prims, acc, acc_root, &index_splits);
+    if (ai) {
+        ai->n_leaves = (uint32_t)prims.size(); ai->n_nodes2 = (uint32_t)acc.size(); ai->on_device = on_device ? 1u : 0u;
+        ai->sah_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - sah_t0).count();
+        ai->sah_device_ms = dev_ms;
+        ai->index_splits = index_splits;
+    }
     const int32_t A = (int32_t)acc.size();
     nodes.resize((size_t)A * 4);
     for (int32_t q = 0; q < A; q++) {
@@ -2747,7 +2768,10 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         std::vector<float4> nodes, geo(d->n_tris * 3ull), mats(d->n_materials * 3ull), ltri(d->n_light_tris * 4ull);
         std::vector<int32_t> leaf_count, tri_mat(d->n_tris);
         int32_t root_fast = 0, root_exact = 0;
-        int depth = convert_bvh(*d, nodes, leaf_count, root_fast, root_exact);
+        AccelInfo ai;
+        int depth = convert_bvh(*d, nodes, leaf_count, root_fast, root_exact, &ai);
+        sc->accel.n_leaves = ai.n_leaves; sc->accel.n_nodes2 = ai.n_nodes2; sc->accel.sah_on_device = ai.on_device;
+        sc->accel.sah_ms = ai.sah_ms; sc->accel.sah_device_ms = ai.sah_device_ms; sc->accel.index_splits = ai.index_splits;
         for (uint32_t i = 0; i < d->n_tris; i++) {
             const crt_triangle& t = d->tris[i];
             // e1 = v2 - v1, e2 = v3 - v1 as DeviceTriangle's constructor computes them (DeviceTriangle.cuh:27-28)
@@ -2876,6 +2900,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->dev.nodes4 = sc->nodes4.p;
         sc->dev.root4 = root4;
         sc->depth4 = depth4;
+        sc->accel.n_nodes4 = (uint32_t)(nodes4.size() / 8); sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
@@ -2921,6 +2946,13 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         delete sc;
         return fail(CRT_ERR_OOM, "crt_scene_create: out of host memory");
     }
+}
+
+int crt_scene_accel_info(crt_scene* sc, crt_accel_info* out)
+{
+    if (!sc || !out) return fail(CRT_ERR_INVALID_ARG, "crt_scene_accel_info: null argument");
+    *out = sc->accel;
+    return CRT_OK;
 }
 
 int crt_scene_destroy(crt_scene* sc)

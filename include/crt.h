@@ -160,6 +160,18 @@ int crt_device_count(int* count);
  * Render.cuh:387-414).  The per-pixel stack allocations of Render.cuh:416-422
  * have no equivalent: traversal stacks live in LDS. */
 int crt_scene_create(const crt_scene_desc* desc, int device, crt_scene** out);
+/* How the acceleration trees of CRT_TRAVERSAL_FAST were built at crt_scene_create: a binned-SAH tree over the reference's leaves
+ * (csrc/crt_accel.h; on the device by default, csrc/crt_accel_build.hip -- CRT_SAH_HOST=1 forces the host builder) collapsed to 4
+ * children per node. */
+typedef struct {
+    uint32_t n_leaves, n_nodes2, n_nodes4, depth2, depth4;
+    uint32_t sah_on_device;   /* 1: built by the device builder, 0: host builder (forced, or the device build could not run) */
+    uint32_t index_splits;    /* ranges whose leaf centroids all coincide (duplicate leaves): split by index -- the only place where the
+                                 device builder's tree may differ from the host builder's (equal leaves on different sides) */
+    float sah_ms;             /* host clock: the whole SAH build (uploads and renumbering included) */
+    float sah_device_ms;      /* HIP events around the level loop (0 for the host builder) */
+} crt_accel_info;
+int crt_scene_accel_info(crt_scene* scene, crt_accel_info* out);
 /* replaces Render::free (Render.cuh:477-487) */
 int crt_scene_destroy(crt_scene* scene);
 
