@@ -187,7 +187,9 @@ def main_rank(args):
 
     cfg = os.path.join(ROOT, "scenes", args.scene, "config.json")
     task = crt.Task(cfg, base_dir=ROOT)
+    c0 = time.perf_counter()
     scene = crt.Scene.from_task(task, args.width, args.height)
+    setup = {"load_and_host_bvh_ms": round((time.perf_counter() - c0) * 1e3, 2)}
     eye = task.eye_pos
     inv_view = crt.get_inverse_view_matrix(task.eye_pos, task.lookat, task.up)
     fov = crt.fov_to_radians(task.fov_y)
@@ -208,6 +210,19 @@ def main_rank(args):
         render2 = crt.Render(scene, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
         render2.seed = args.seed
         render2.traversal = trav
+
+    if rank == 0:
+        # scene set-up on the device (not part of a step): the reference BVH (byte-identical to the host build above) and the SAH tree of
+        # the FAST traversal, both built on the GPU -- crt_host_scene_set_bvh_device / crt_scene_create
+        s2 = crt.Scene.from_task(task, args.width, args.height, bvh_device=local_rank)
+        s2 = crt.Scene.from_task(task, args.width, args.height, bvh_device=local_rank)  # (second build: code objects loaded)
+        same = s2.nodes().tobytes() == scene.nodes().tobytes() and s2.triangles().tobytes() == scene.triangles().tobytes()
+        bi = s2.bvh_build_info
+        ai = render.accel_info()
+        setup.update({"bvh_device": {"total_ms": round(bi["total_ms"], 2), "level_loop_ms": round(bi["device_ms"], 2), "host_sorts": bi["host_sorts"],
+                                     "host_triangles": bi["host_triangles"], "byte_identical_to_host_build": bool(same)},
+                      "sah_tree": {"on_device": bool(ai["sah_on_device"]), "ms": round(ai["sah_ms"], 2), "leaves": ai["n_leaves"], "nodes4": ai["n_nodes4"]}})
+        s2.free()
 
     def step():
         if multi:
@@ -455,6 +470,7 @@ def main_rank(args):
                            "launched_by": "torch.distributed.run" if (world > 1 and not os.environ.get("CRT_BENCH_SPAWNED")) else
                                           ("bench.py (self-started ranks)" if world > 1 else "single process")},
             "build_flags": B.built_flags(),
+            "scene_setup": setup,
             "rays_untraced_per_frame_rank0": int(untraced_local),
             "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
             "all_rays_traced": all_traced,

@@ -140,11 +140,12 @@ class Scene:
             pass
 
     @classmethod
-    def from_task(cls, task, width=None, height=None):
+    def from_task(cls, task, width=None, height=None, bvh_device=None):
+        """render_view()'s scene set-up (src/main.cu:119-145,276); bvh_device=k builds the BVH on GPU k (same arrays)."""
         s = cls(width or task.width, height or task.height)
         for obj, mtl in task.OBJ_paths:
             s.add_obj(obj, mtl)
-        s.set_BVH(task.bvh_thresh_n)
+        s.set_BVH(task.bvh_thresh_n, device=bvh_device)
         return s
 
 

@@ -671,7 +671,7 @@ __device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& 
                 L.best_t = w0 ? t0 : L.best_t; L.best_tri = w0 ? it : L.best_tri; L.best_leaf = w0 ? it : L.best_leaf;
                 const bool w1 = a1 && (t1 < L.best_t || (t1 == L.best_t && it > L.best_leaf));
                 L.best_t = w1 ? t1 : L.best_t; L.best_tri = w1 ? it + 1 : L.best_tri; L.best_leaf = w1 ? it : L.best_leaf;
-                if (MODE == 0) L.bound = (w0 || w1) ? prune_bound(L.best_t) : L.bound;
+                if (MODE == 0) L.bound = (w0 || w1) ? prune_bound(L.best_t, L.r.o, L.r.inv) : L.bound;
             }
             for (int i = it + 2; i < it + n && !done; i++) { // only with bvh_thresh_n > 2
                 if (STATS) cnt.tests++;
@@ -681,7 +681,7 @@ __device__ __forceinline__ bool trav_step(const DevScene& sc, TravLane& L, int& 
                         if (L.t_limit - t > CRT_EPSILON) { L.best_t = t; L.best_tri = i; done = true; }
                     } else if (t < L.best_t || (t == L.best_t && it > L.best_leaf)) {
                         L.best_t = t; L.best_tri = i; L.best_leaf = it;
-                        if (MODE == 0) L.bound = prune_bound(t);
+                        if (MODE == 0) L.bound = prune_bound(t, L.r.o, L.r.inv);
                     }
                 }
             }
@@ -748,7 +748,7 @@ __device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint3
     if (L.any_hit) {
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) return TR_IDLE;
-        L.bound = prune_bound(L.t_limit);
+        L.bound = prune_bound(L.t_limit, L.r.o, L.r.inv);
     }
     return L.ref >= 0 ? TR_INNER : TR_LEAF;
 }
@@ -1727,7 +1727,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #endif
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
-                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w) : FLT_MAX;
+                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w, o, inv) : FLT_MAX;
                 bool done = false;
                 if (MODE == 1) {
                     const float4 qb = S.B[id];
@@ -2004,11 +2004,12 @@ __global__ __launch_bounds__(256) void k_preview(const AParams A, const float sc
 // ------------------------------------------------------------ test kernels --
 // crt_intersect: loads n host rays into the first n pool slots (direction normalised as Ray's
 // constructor does, Ray.cuh:12-13) so that the production trace kernel answers them.
-__global__ __launch_bounds__(256) void k_fill_rays(Pool pl, uint32_t n, const float* o, const float* d)
+__global__ __launch_bounds__(256) void k_fill_rays(Pool pl, uint32_t n, const float* o, const float* d, const bool raw_dir)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    F3 dir = unit3(f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]));
+    F3 dir = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    if (!raw_dir) dir = unit3(dir);
     pl.ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
     pl.rd[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)RAY_CLOSEST));
     pl.res[i] = make_float2(FLT_MAX, __int_as_float(-1));
@@ -3088,6 +3089,9 @@ int crt_preview(crt_scene* sc, uint8_t* out_rgb, float* out_mean, uint32_t* samp
 int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* dirs, uint32_t traversal, int32_t* out_tri, float* out_t)
 {
     if (!sc || !origins || !dirs || !out_tri || !out_t) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: null argument");
+    const bool raw_dir = (traversal & CRT_INTERSECT_RAW_DIRECTIONS) != 0;
+    const bool force_exact = (traversal & CRT_INTERSECT_FORCE_EXACT) != 0;
+    traversal &= ~(uint32_t)(CRT_INTERSECT_RAW_DIRECTIONS | CRT_INTERSECT_FORCE_EXACT);
     if (traversal != CRT_TRAVERSAL_FAST && traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: unknown traversal mode");
     if (n == 0) return CRT_OK;
     try {
@@ -3100,7 +3104,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
         Pool pool;
         std::memset(&pool, 0, sizeof(pool));
         pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.res = sc->p_res.p; pool.n = n;
-        hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p);
+        hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p, raw_dir);
         HIP_CHECK(hipGetLastError());
         if (choose_pipeline(sc) == 4) {
             // the rays walk the traversal phases of the render kernel itself (k_mega3 in query form: work item = ray)
@@ -3125,6 +3129,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             P.nslots = 1; P.nslots_div = make_fastdiv(1); P.tiles_x = 1; P.tiles_x_div = make_fastdiv(1); P.lsn_div = make_fastdiv(1);
             M3.M.sc = sc->dev; M3.M.counters = sc->counters.p; M3.M.spill_stride = lanes; M3.M.stack_cap = POOL_LV;
             M3.spill = (int*)sc->spill[0].p;
+            M3.force_exact = force_exact ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), nullptr));
             if (reference) hipLaunchKernelGGL((k_mega3<1, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
             else hipLaunchKernelGGL((k_mega3<0, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);

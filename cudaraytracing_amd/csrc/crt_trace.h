@@ -43,13 +43,24 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, const RayT& r, b
     return t_enter <= t_exit + CRT_EPSILON && t_exit >= 0;
 }
 
-// Pruning bound: a box may be skipped only if it starts beyond this.  The slack (0.1 % + 1e-3) absorbs the rounding
-// difference between the slab arithmetic and the Moeller-Trumbore t of a triangle inside the box.  Not a theorem:
-// t = (s2 . e2) / det has no bounded relative error when det -> 0 (ray in the triangle's plane, sliver triangle), so a
-// triangle whose computed t undercuts its own leaf box by more than the slack could be pruned here and accepted by the
-// exhaustive traversal.  Probed adversarially (tests/test_adversarial_traversal.py: grazing angles 0 ... 1e-2, aspect
-// ratios to 1e7, offsets to 3e7 -- no difference found) and re-checked by bench.py on a slice of every benchmark run.
-__device__ __forceinline__ float prune_bound(float t) { return t + (absf(t) * 1.0e-3f + 1.0e-3f); }
+// Pruning bound: a box may be skipped only if its slab entry distance lies beyond this.  Two slacks on top of the distance t of
+// the best hit (or of the light, for shadow rays):
+//   * 0.1 % + 1e-3: the rounding difference between the slab arithmetic and the Moeller-Trumbore t of a well-conditioned pair;
+//   * 1e-4 x (max_a |o_a / d_a| + |t|): the hit point Moeller-Trumbore accepts can lie a few ulp of its coordinates OUTSIDE the
+//     triangle's box; coordinate a of a point of the ray is at most |o_a| + |t| |d_a|, and along an axis the ray barely moves in,
+//     a displacement of k ulp of that is a distance difference of k ulp x (|o_a| / |d_a| + |t|).  Found by the full-size C3 frame (one ray in 3.5e9: a ray with d.y = -7.6e-4 grazing the shared edge
+//     of two triangles of a light sphere; the nearer triangle's accepted hit lay 1.7e-5 above its box, i.e. its box is entered at
+//     t + 0.022 -- beyond the old bound of t' + 0.011 after the farther triangle had been found first): FAST returned the
+//     farther triangle, REFERENCE the nearer one.  1e-4 of the coordinates is 40 x that case's displacement.
+// Still not a theorem (t = (s2 . e2) / det has no bounded error when det -> 0), but it now scales with the two things the error
+// scales with.  Probed adversarially (tests/test_adversarial_traversal.py, the C3 ray as a known-answer test) and re-checked
+// by bench.py on a slice of every benchmark run; tests/test_production_sizes.py compares FAST with REFERENCE on the full C2
+// and C3 frames.  Rays with a zero direction component get an infinite bound (no pruning).
+__device__ __forceinline__ float prune_bound(float t, const F3 o, const F3 inv)
+{
+    const float lever = fmaxf(fmaxf(absf(o.x * inv.x), absf(o.y * inv.y)), absf(o.z * inv.z)); // max_a |o_a / d_a|
+    return t + (absf(t) * 1.0e-3f + 1.0e-3f) + 1.0e-4f * (lever + absf(t));
+}
 
 // Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 + the t > EPSILON
 // filter of DeviceBVHNode::hit (DeviceBVH.cuh:37).  Returns true for an accepted hit.

@@ -339,6 +339,8 @@ struct LightSample {
     float inv_pdf;
 };
 /* reference: include/Ray.cuh:12-15 */
+static std::vector<float>* g_ray_log = nullptr;
+
 struct Ray {
     V3 origin, dir, inv_dir;
     Ray(V3 o, V3 d) : origin(o)
@@ -406,6 +408,15 @@ struct Tracer {
     }
     /* reference: include/DeviceBVH.cuh:128-170 (traversal) and :31-43 (leaf) */
     HitPayload intersect(V3 origin, V3 dir, V3 inv_dir)
+    {
+        HitPayload h = intersect_(origin, dir, inv_dir);
+        if (g_ray_log) { /* diagnostic ray log (orc_ray_log_*): origin, direction, hit distance, hit triangle */
+            const float rec[8] = {origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, h.t, (float)(h.happend ? h.tri : -1)};
+            g_ray_log->insert(g_ray_log->end(), rec, rec + 8);
+        }
+        return h;
+    }
+    HitPayload intersect_(V3 origin, V3 dir, V3 inv_dir)
     {
         st.rays++;
         bvh_stack.clear();
@@ -720,6 +731,17 @@ void orc_inverse_view(const float eye[3], const float lookat[3], const float up[
     out[0] = r.x; out[1] = r.y; out[2] = r.z; /* column 0 */
     out[3] = u.x; out[4] = u.y; out[5] = u.z; /* column 1 */
     out[6] = f.x; out[7] = f.y; out[8] = f.z; /* column 2 */
+}
+
+/* diagnostic: every ray orc_render traces between orc_ray_log_begin() and orc_ray_log_end() (8 floats per ray) */
+extern "C" void orc_ray_log_begin(void) { delete g_ray_log; g_ray_log = new std::vector<float>(); }
+extern "C" uint64_t orc_ray_log_end(float* out, uint64_t cap_rays)
+{
+    if (!g_ray_log) return 0;
+    const uint64_t n = g_ray_log->size() / 8;
+    if (out) std::memcpy(out, g_ray_log->data(), (size_t)std::min<uint64_t>(n, cap_rays) * 32);
+    if (out) { delete g_ray_log; g_ray_log = nullptr; }
+    return n;
 }
 
 /* reference: include/Render.cuh:330-354 (view_render_kernel) driven as a pixel loop */

@@ -293,3 +293,40 @@ def test_scene_description_must_be_one_tree():
     h = C.c_void_p()
     assert capi.lib().crt_scene_create(C.byref(bad), 0, C.byref(h)) == -1
     assert b"does not reach" in capi.lib().crt_last_error()
+
+
+def test_the_c3_ray_that_the_old_pruning_bound_lost():
+    """Known answer from the full-size C3 frame (veach-mis 800x600 spp 1024, pixel (639, 158), 1 ray in 3.5e9): direction
+    component d.y = -7.6e-4, the ray grazes the shared edge of two triangles of a light sphere; Moeller-Trumbore accepts the
+    nearer triangle (1985, t = 10.44168) at a point 1.7e-5 ABOVE that triangle's box, so the box is entered at t + 0.022 --
+    beyond the old bound t' + 0.011 once the farther triangle (2139, t' = 10.442408) had been found.  Every traversal form must
+    return the reference's answer; neighbours of the ray (a few ulp around origin and direction) are probed too."""
+    name = "veach-mis"
+    t = util.task(name)
+    osc = util.oracle_scene(name)
+    r = crt.Render(util.host_scene(name), 1, t.P_RR, t.light_sample_n)
+    try:
+        bits = np.array([3231711228, 1087552060, 3236092846, 1055547749, 3125281698, 1063492088], dtype=np.uint32)
+        rng = np.random.RandomState(1)
+        n = 4096
+        ob = np.tile(bits[:3], (n, 1)).astype(np.int64)
+        db = np.tile(bits[3:], (n, 1)).astype(np.int64)
+        ob[1:] += rng.randint(-4, 5, (n - 1, 3))
+        db[1:] += rng.randint(-64, 65, (n - 1, 3))
+        o = ob.astype(np.uint32).view(np.float32)
+        d = db.astype(np.uint32).view(np.float32)
+        # the oracle normalises directions as Ray's constructor does; the queries below must do the same (no RAW flag): both sides
+        # see the same float direction
+        otri, ot, _ = osc.intersect(o, d)
+        seen = set()
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT):
+            tri, tt = r.intersect(o, d, traversal=mode)
+            bad = np.nonzero((tri != otri) | (util.bits(tt) != util.bits(ot)))[0]
+            assert bad.size == 0, (mode, bad[:5], tri[bad[:5]], otri[bad[:5]])
+            seen |= set(int(v) for v in np.unique(tri))
+        assert 1985 in seen  # the probes do hit the triangle in question
+        # and the logged ray itself, direction taken as it is
+        tri, tt = r.intersect(o[:1], d[:1], traversal=crt.TRAVERSAL_FAST | crt.INTERSECT_RAW_DIRECTIONS)
+        assert tri[0] == 1985 and util.bits(tt)[0] == 1093079327
+    finally:
+        r.free()
