@@ -15,7 +15,7 @@ FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4
 FLAG_TRACE_ALL = 8
 GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
-INTERSECT_RAW_DIRECTIONS, INTERSECT_FORCE_EXACT = 0x100, 0x200
+INTERSECT_RAW_DIRECTIONS, INTERSECT_FORCE_EXACT, INTERSECT_VISIBILITY = 0x100, 0x200, 0x400
 TILE = 8
 
 

@@ -274,6 +274,18 @@ class Render:
                                             capi.ptr(t)), "crt_intersect")
         return tri, t
 
+    def blocked(self, origins, dirs, limits, traversal=None):
+        """blocked() of Render.cuh:19-27 for n visibility rays with t_to_light = limits: (blocked, blocking triangle or -1)"""
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = o.shape[0]
+        tri = np.zeros(n, dtype=np.int32)
+        t = np.array(limits, dtype=np.float32).reshape(n).copy()
+        capi.check(capi.lib().crt_intersect(self._h, n, capi.ptr(o), capi.ptr(d),
+                                            (self.traversal if traversal is None else traversal) | capi.INTERSECT_VISIBILITY,
+                                            capi.ptr(tri), capi.ptr(t)), "crt_intersect")
+        return t != 0.0, tri
+
     def save_frame_buffer(self, save_path):
         if self.frame_buffer is None:
             raise RuntimeError("save_frame_buffer before run_view")

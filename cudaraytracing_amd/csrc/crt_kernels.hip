@@ -1351,7 +1351,7 @@ __device__ __forceinline__ bool query_C(const LParams& P, const uint32_t g, cons
     pl.id[g] = make_uint4(0u, 0u, item, 0u);
     pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8));
     const float4 o = P.q_o[item], d = P.q_d[item];
-    nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = RF_QUERY;
+    nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = o.w; nr.kind = __float_as_uint(d.w); nr.flags = RF_QUERY;
     return true;
 }
 
@@ -1727,7 +1727,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #endif
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
+#ifdef CRT_VIS_NOPRUNE
+                const float bound = ((qd & RF_HASHIT) && !(qd & RF_ANYHIT)) ? prune_bound(qa.w, o, inv) : FLT_MAX;
+#else
                 const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w, o, inv) : FLT_MAX;
+#endif
                 bool done = false;
                 if (MODE == 1) {
                     const float4 qb = S.B[id];
@@ -2004,14 +2008,15 @@ __global__ __launch_bounds__(256) void k_preview(const AParams A, const float sc
 // ------------------------------------------------------------ test kernels --
 // crt_intersect: loads n host rays into the first n pool slots (direction normalised as Ray's
 // constructor does, Ray.cuh:12-13) so that the production trace kernel answers them.
-__global__ __launch_bounds__(256) void k_fill_rays(Pool pl, uint32_t n, const float* o, const float* d, const bool raw_dir)
+// limits != nullptr: the rays are visibility rays (blocked(), Render.cuh:19-27) with these t_to_light values.
+__global__ __launch_bounds__(256) void k_fill_rays(Pool pl, uint32_t n, const float* o, const float* d, const bool raw_dir, const float* limits)
 {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     F3 dir = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     if (!raw_dir) dir = unit3(dir);
-    pl.ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], 0.0f);
-    pl.rd[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)RAY_CLOSEST));
+    pl.ro[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], limits ? limits[i] : 0.0f);
+    pl.rd[i] = make_float4(dir.x, dir.y, dir.z, __uint_as_float((uint32_t)(limits ? RAY_SHADOW : RAY_CLOSEST)));
     pl.res[i] = make_float2(FLT_MAX, __int_as_float(-1));
 }
 
@@ -3091,20 +3096,32 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
     if (!sc || !origins || !dirs || !out_tri || !out_t) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: null argument");
     const bool raw_dir = (traversal & CRT_INTERSECT_RAW_DIRECTIONS) != 0;
     const bool force_exact = (traversal & CRT_INTERSECT_FORCE_EXACT) != 0;
-    traversal &= ~(uint32_t)(CRT_INTERSECT_RAW_DIRECTIONS | CRT_INTERSECT_FORCE_EXACT);
+    const bool any_hit = (traversal & CRT_INTERSECT_VISIBILITY) != 0;
+    traversal &= ~(uint32_t)(CRT_INTERSECT_RAW_DIRECTIONS | CRT_INTERSECT_FORCE_EXACT | CRT_INTERSECT_VISIBILITY);
     if (traversal != CRT_TRAVERSAL_FAST && traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: unknown traversal mode");
     if (n == 0) return CRT_OK;
     try {
         HIP_CHECK(hipSetDevice(sc->device));
-        DevBuf<float> o, d;
+        DevBuf<float> o, d, lim;
         o.alloc(n * 3ull); d.alloc(n * 3ull);
         HIP_CHECK(hipMemcpy(o.p, origins, n * 12ull, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(d.p, dirs, n * 12ull, hipMemcpyHostToDevice));
+        if (any_hit) { lim.alloc(n); HIP_CHECK(hipMemcpy(lim.p, out_t, n * 4ull, hipMemcpyHostToDevice)); }
+        // blocked() of Render.cuh:19-27 from a finished visibility ray (limit = out_t[i] on entry): REFERENCE compares the closest
+        // hit, FAST recorded a hit only if it passes the comparison (shadow_blocked)
+        const bool reference_mode = traversal == CRT_TRAVERSAL_REFERENCE;
+        auto answer = [&](uint32_t i, float T, int32_t tri) {
+            if (!any_hit) { out_t[i] = T; out_tri[i] = tri; return; }
+            const float tl = out_t[i];
+            const bool blocked = reference_mode ? (tl - T > CRT_EPSILON) : (tri >= 0 || tl - FLT_MAX > CRT_EPSILON);
+            out_t[i] = blocked ? 1.0f : 0.0f;
+            out_tri[i] = blocked ? tri : -1;
+        };
         sc->p_ro.ensure(n); sc->p_rd.ensure(n); sc->p_res.ensure(n);
         Pool pool;
         std::memset(&pool, 0, sizeof(pool));
         pool.ro = sc->p_ro.p; pool.rd = sc->p_rd.p; pool.res = sc->p_res.p; pool.n = n;
-        hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p, raw_dir);
+        hipLaunchKernelGGL(k_fill_rays, dim3((n + 255) / 256), dim3(256), 0, 0, pool, n, o.p, d.p, raw_dir, any_hit ? lim.p : (const float*)nullptr);
         HIP_CHECK(hipGetLastError());
         if (choose_pipeline(sc) == 4) {
             // the rays walk the traversal phases of the render kernel itself (k_mega3 in query form: work item = ray)
@@ -3138,8 +3155,9 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             std::vector<float4> res(n);
             HIP_CHECK(hipMemcpy(res.data(), sc->L.p, n * sizeof(float4), hipMemcpyDeviceToHost));
             for (uint32_t i = 0; i < n; i++) {
-                out_t[i] = res[i].x;
-                std::memcpy(&out_tri[i], &res[i].y, 4);
+                int32_t tri;
+                std::memcpy(&tri, &res[i].y, 4);
+                answer(i, res[i].x, tri);
             }
             return CRT_OK;
         }
@@ -3150,8 +3168,9 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
         std::vector<float2> res(n);
         HIP_CHECK(hipMemcpy(res.data(), sc->p_res.p, n * sizeof(float2), hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; i++) {
-            out_t[i] = res[i].x;
-            std::memcpy(&out_tri[i], &res[i].y, 4);
+            int32_t tri;
+            std::memcpy(&tri, &res[i].y, 4);
+            answer(i, res[i].x, tri);
         }
         return CRT_OK;
     } catch (const HipFail& f) {

@@ -44,22 +44,29 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, const RayT& r, b
 }
 
 // Pruning bound: a box may be skipped only if its slab entry distance lies beyond this.  Two slacks on top of the distance t of
-// the best hit (or of the light, for shadow rays):
+// the best hit (or of the light, for visibility rays):
 //   * 0.1 % + 1e-3: the rounding difference between the slab arithmetic and the Moeller-Trumbore t of a well-conditioned pair;
-//   * 1e-4 x (max_a |o_a / d_a| + |t|): the hit point Moeller-Trumbore accepts can lie a few ulp of its coordinates OUTSIDE the
-//     triangle's box; coordinate a of a point of the ray is at most |o_a| + |t| |d_a|, and along an axis the ray barely moves in,
-//     a displacement of k ulp of that is a distance difference of k ulp x (|o_a| / |d_a| + |t|).  Found by the full-size C3 frame (one ray in 3.5e9: a ray with d.y = -7.6e-4 grazing the shared edge
-//     of two triangles of a light sphere; the nearer triangle's accepted hit lay 1.7e-5 above its box, i.e. its box is entered at
-//     t + 0.022 -- beyond the old bound of t' + 0.011 after the farther triangle had been found first): FAST returned the
-//     farther triangle, REFERENCE the nearer one.  1e-4 of the coordinates is 40 x that case's displacement.
-// Still not a theorem (t = (s2 . e2) / det has no bounded error when det -> 0), but it now scales with the two things the error
-// scales with.  Probed adversarially (tests/test_adversarial_traversal.py, the C3 ray as a known-answer test) and re-checked
-// by bench.py on a slice of every benchmark run; tests/test_production_sizes.py compares FAST with REFERENCE on the full C2
-// and C3 frames.  Rays with a zero direction component get an infinite bound (no pruning).
+//   * CRT_PRUNE_REL x reach x steep, reach = max |origin coordinate| + |t| (no coordinate of a point of the ray up to t is larger),
+//     steep = max |1 / direction component|: the hit Moeller-Trumbore accepts can lie OUTSIDE the triangle's box by a displacement
+//     that scales with the coordinates in play, and along an axis the ray barely moves in that displacement is a distance
+//     difference of displacement / |d_axis|.  Found by full-size FAST-against-REFERENCE frames: one ray in 3.5e9 of C3 (d.y =
+//     -7.6e-4, grazing the shared edge of two triangles of a light sphere; the nearer triangle's hit lay 1.7e-5 above its box, i.e.
+//     the box is entered at t + 0.022) and four more in 1.2e11 rays of C5 with a per-axis form of the term.
+// NOT a theorem, and no factor makes it one: for a ray lying in a triangle's plane (det -> 0) t = (s2 . e2) / det is a ratio of
+// rounding noise, and the reference accepts it when the equally noisy barycentrics land in (0,1).  With the shipped factor the soak
+// (tools/soak_fast_vs_reference.py) finds 2 lost visibility rays in 3.66e11 rays of veach-mis (cos = 5e-6 / 3e-6 against a small
+// sphere triangle; t lands 0.045 / 0.035 in front of the leaf box, 3.5 / 7.7 x the slack) and 0 in 2.4e10 of cornell-box; the
+// margin histogram of tools/margin_hist.py shows a tail ~ s^-0.7 on veach-mis (factor 1e-3: a fifth of the events for +8.5 % frame
+// time) and no tail at all on cornell-box.  DESIGN.md section 4.3 has the numbers; include/crt.h states the contract; the lost
+// rays are known answers in tests/test_adversarial_traversal.py.  Rays with a zero direction component get an infinite bound.
+#ifndef CRT_PRUNE_REL
+#define CRT_PRUNE_REL 1.0e-4f
+#endif
 __device__ __forceinline__ float prune_bound(float t, const F3 o, const F3 inv)
 {
-    const float lever = fmaxf(fmaxf(absf(o.x * inv.x), absf(o.y * inv.y)), absf(o.z * inv.z)); // max_a |o_a / d_a|
-    return t + (absf(t) * 1.0e-3f + 1.0e-3f) + 1.0e-4f * (lever + absf(t));
+    const float reach = fmaxf(fmaxf(absf(o.x), absf(o.y)), absf(o.z)) + absf(t);
+    const float steep = fmaxf(fmaxf(absf(inv.x), absf(inv.y)), absf(inv.z));
+    return t + (absf(t) * 1.0e-3f + 1.0e-3f) + CRT_PRUNE_REL * reach * steep;
 }
 
 // Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 + the t > EPSILON

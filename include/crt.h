@@ -100,14 +100,18 @@ typedef struct {
 } crt_camera;
 
 enum {
-    CRT_TRAVERSAL_FAST = 0,      /* ordered, pruned, any-hit shadow rays.  Ordering, the 4-wide tree and any-hit are provably result-neutral;
-                                    the pruning rule (csrc/crt_trace.h: skip a box entered beyond best_t + 0.1 % + 1e-3 + 1e-4 (max_a |o_a / d_a| +
-                                    best_t)) is exact unless a Moeller-Trumbore hit disagrees with its own leaf box by more than that slack,
-                                    which the arithmetic does not exclude for degenerate ray / triangle pairs (round 2 found one such ray in
-                                    3.5e9 with the earlier, distance-only slack; it is a known-answer test now).  Status: bit-identical to
-                                    REFERENCE on the full C2 / C3 / C4 frames, on rank 0's share of C5, on every scene and every adversarial
-                                    probe of the test-suite (tests/test_adversarial_traversal.py, tests/test_production_sizes.py), and
-                                    bench.py re-checks a slice of the benchmark frame against REFERENCE in every run */
+    CRT_TRAVERSAL_FAST = 0,      /* ordered, pruned, any-hit visibility rays.  Ordering, the 4-wide tree and any-hit are provably result-neutral;
+                                    the pruning rule (csrc/crt_trace.h: skip a box entered beyond t_ref + 0.1 % + 1e-3 + 1e-4 x reach x steep, reach
+                                    = max |origin coordinate| + t_ref, steep = max |1 / direction component|) is exact unless a
+                                    Moeller-Trumbore hit lies further in front of its own leaf box than that slack, which happens for rays
+                                    lying in the plane of a triangle (det -> 0: unbounded error, and the reference has no determinant
+                                    threshold).  MEASURED (tools/soak_fast_vs_reference.py, profiles/r02_soak_fast_vs_reference.jsonl): 2 rays in
+                                    3.66e11 on full 1920x1080x4096 veach-mis frames (tessellated spheres; each changes one next-event sample:
+                                    the last bit of one pixel), 0 in 2.4e10 on full 3840x2160x256 cornell-box frames; a larger factor only thins
+                                    them out.  Bit-identical to REFERENCE on every frame and probe of the test-suite
+                                    (tests/test_production_sizes.py, tests/test_adversarial_traversal.py -- two lost rays are kept there as
+                                    known answers), and bench.py re-checks a slice of the benchmark frame against REFERENCE in every run.
+                                    Use CRT_TRAVERSAL_REFERENCE where bit-exactness must be unconditional. */
     CRT_TRAVERSAL_REFERENCE = 1  /* exhaustive traversal in the reference's visit order (DeviceBVH.cuh:128-170) */
 };
 enum {
@@ -264,6 +268,10 @@ int crt_multi_frame_device(crt_multi* multi, void** d_rgb, void** d_mean, int* d
  * constructor does (Ray.cuh:12-15). out_tri: BVH-order triangle index or -1. */
 #define CRT_INTERSECT_RAW_DIRECTIONS 0x100u /* OR into `traversal`: take dirs as they are (already a Ray's direction), do not normalise again */
 #define CRT_INTERSECT_FORCE_EXACT 0x200u     /* OR into `traversal`: as CRT_FLAG_FORCE_EXACT for the queries (test hook) */
+/* OR into `traversal`: the rays are visibility rays -- blocked() of Render.cuh:19-27.  out_t[i] holds t_to_light on entry; on return
+ * out_t[i] = 1.0f if the ray is blocked (t_to_light - closest.t > EPSILON) else 0.0f and out_tri[i] = a blocking triangle or -1
+ * (REFERENCE: the closest hit; FAST: the first one the any-hit traversal met). */
+#define CRT_INTERSECT_VISIBILITY 0x400u
 int crt_intersect(crt_scene* scene, uint32_t n, const float* origins, const float* dirs, uint32_t traversal,
                   int32_t* out_tri, float* out_t);
 

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <sstream>
 #include <string>
@@ -340,6 +341,13 @@ struct LightSample {
 };
 /* reference: include/Ray.cuh:12-15 */
 static std::vector<float>* g_ray_log = nullptr;
+static float g_ray_log_limit = std::numeric_limits<float>::quiet_NaN(); /* the visibility limit of the ray being logged (NaN: a closest-hit ray) */
+#define ORC_RAY_LOG_FLOATS 10
+/* diagnostic (orc_margin_hist): how far in front of its own leaf box the hit a query's answer rests on lies, in units of reach x steep
+ * (the pruning slack of the HIP path's CRT_TRAVERSAL_FAST is a multiple of that product): bin b counts answers with
+ * 10^(b/2 - 10) <= (box entry - t_ref) / (reach * steep) < 10^((b+1)/2 - 10); t_ref = the hit distance of a closest-hit ray, the limit of a
+ * blocked visibility ray.  Bin 0 also takes everything below, bin 23 everything above; [24] = answers with a hit, [25] = all rays. */
+static uint64_t* g_margin_hist = nullptr;
 
 struct Ray {
     V3 origin, dir, inv_dir;
@@ -407,18 +415,48 @@ struct Tracer {
         return t_enter <= t_exit + EPSILON && t_exit >= 0;
     }
     /* reference: include/DeviceBVH.cuh:128-170 (traversal) and :31-43 (leaf) */
+    /* diagnostic: t_enter of hit_aabb for the leaf the closest hit of the last intersect_() was found in */
+    int hit_leaf = -1;
+    float leaf_entry(V3 origin, V3 dir, V3 inv_dir) const
+    {
+        if (hit_leaf < 0) return 0.0f;
+        const BVHNode& node = sc.nodes[hit_leaf];
+        V3 OA = node.AA - origin, OB = node.BB - origin;
+        V3 t_min = cwise(OA, inv_dir), t_max = cwise(OB, inv_dir);
+        if (dir.x < 0) std::swap(t_min.x, t_max.x);
+        if (dir.y < 0) std::swap(t_min.y, t_max.y);
+        if (dir.z < 0) std::swap(t_min.z, t_max.z);
+        return maxf(maxf(t_min.x, t_min.y), t_min.z);
+    }
     HitPayload intersect(V3 origin, V3 dir, V3 inv_dir)
     {
         HitPayload h = intersect_(origin, dir, inv_dir);
+        if (g_margin_hist) {
+            g_margin_hist[25]++;
+            const bool vis = g_ray_log_limit == g_ray_log_limit;
+            if (h.happend && (!vis || g_ray_log_limit - h.t > EPSILON)) {
+                g_margin_hist[24]++;
+                const double t_ref = vis ? g_ray_log_limit : h.t;
+                const double reach = std::max(std::max(std::fabs((double)origin.x), std::fabs((double)origin.y)), std::fabs((double)origin.z)) + std::fabs(t_ref);
+                const double steep = std::max(std::max(std::fabs((double)inv_dir.x), std::fabs((double)inv_dir.y)), std::fabs((double)inv_dir.z));
+                const double m = ((double)leaf_entry(origin, dir, inv_dir) - t_ref) / (reach * steep);
+                if (m > 0) {
+                    int b = (int)std::floor((std::log10(m) + 10.0) * 2.0);
+                    g_margin_hist[b < 0 ? 0 : (b > 23 ? 23 : b)]++;
+                }
+            }
+        }
         if (g_ray_log) { /* diagnostic ray log (orc_ray_log_*): origin, direction, hit distance, hit triangle */
-            const float rec[8] = {origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, h.t, (float)(h.happend ? h.tri : -1)};
-            g_ray_log->insert(g_ray_log->end(), rec, rec + 8);
+            const float rec[ORC_RAY_LOG_FLOATS] = {origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, h.t, (float)(h.happend ? h.tri : -1), g_ray_log_limit,
+                                                   h.happend ? leaf_entry(origin, dir, inv_dir) : 0.0f};
+            g_ray_log->insert(g_ray_log->end(), rec, rec + ORC_RAY_LOG_FLOATS);
         }
         return h;
     }
     HitPayload intersect_(V3 origin, V3 dir, V3 inv_dir)
     {
         st.rays++;
+        hit_leaf = -1;
         bvh_stack.clear();
         bvh_stack.push(sc.root);
         HitPayload closest;
@@ -435,7 +473,7 @@ struct Tracer {
                     HitPayload tmp = tri_intersect(i, origin, dir);
                     if (tmp.t > EPSILON && tmp.t < payload.t) payload = tmp;
                 }
-                if (payload.t < closest.t) closest = payload;
+                if (payload.t < closest.t) { closest = payload; hit_leaf = cur; }
             } else {
                 st.inner_pops++;
                 bool hl = hit_aabb(node.lc, origin, dir, inv_dir);
@@ -571,7 +609,9 @@ V3 cast_ray_v2(PathCtx& c, Ray ray)
                     Ray back(pos, dir);
                     /* blocked(): Render.cuh:19-27 with t_to_light = dist.x()/dir.x() (:272) */
                     tr.st.shadow_rays++;
+                    g_ray_log_limit = dist.x / dir.x;
                     HitPayload sh = tr.intersect(back.origin, back.dir, back.inv_dir);
+                    g_ray_log_limit = std::numeric_limits<float>::quiet_NaN();
                     bool is_blocked = (dist.x / dir.x) - sh.t > EPSILON;
                     if (!is_blocked) {
                         V3 L_i = ls.emit;
@@ -733,15 +773,23 @@ void orc_inverse_view(const float eye[3], const float lookat[3], const float up[
     out[6] = f.x; out[7] = f.y; out[8] = f.z; /* column 2 */
 }
 
-/* diagnostic: every ray orc_render traces between orc_ray_log_begin() and orc_ray_log_end() (8 floats per ray) */
+/* diagnostic: every ray orc_render traces between orc_ray_log_begin() and orc_ray_log_end(); ORC_RAY_LOG_FLOATS (10) floats per ray:
+ * origin, direction, hit distance, hit triangle, visibility limit (NaN for a closest-hit ray), box-entry distance of the hit leaf */
 extern "C" void orc_ray_log_begin(void) { delete g_ray_log; g_ray_log = new std::vector<float>(); }
 extern "C" uint64_t orc_ray_log_end(float* out, uint64_t cap_rays)
 {
     if (!g_ray_log) return 0;
-    const uint64_t n = g_ray_log->size() / 8;
-    if (out) std::memcpy(out, g_ray_log->data(), (size_t)std::min<uint64_t>(n, cap_rays) * 32);
+    const uint64_t n = g_ray_log->size() / ORC_RAY_LOG_FLOATS;
+    if (out) std::memcpy(out, g_ray_log->data(), (size_t)std::min<uint64_t>(n, cap_rays) * ORC_RAY_LOG_FLOATS * sizeof(float));
     if (out) { delete g_ray_log; g_ray_log = nullptr; }
     return n;
+}
+
+/* diagnostic: see g_margin_hist.  orc_margin_hist(NULL) starts (and zeroes) the histogram, orc_margin_hist(out26) copies and stops it */
+extern "C" void orc_margin_hist(uint64_t* out)
+{
+    if (!out) { delete[] g_margin_hist; g_margin_hist = new uint64_t[26](); return; }
+    if (g_margin_hist) { std::memcpy(out, g_margin_hist, 26 * sizeof(uint64_t)); delete[] g_margin_hist; g_margin_hist = nullptr; }
 }
 
 /* reference: include/Render.cuh:330-354 (view_render_kernel) driven as a pixel loop */

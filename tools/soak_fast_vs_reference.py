@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Soak test of CRT_TRAVERSAL_FAST against the exhaustive CRT_TRAVERSAL_REFERENCE: renders the shards of a frame in both modes and
+counts the pixel slots whose float mean differs (expected: 0).  One line of JSON per shard."""
+import argparse, ctypes as C, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import cudaraytracing_amd as crt
+from cudaraytracing_amd import _capi as capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="veach-mis")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=4096)
+ap.add_argument("--ranks", type=int, default=8)
+ap.add_argument("--seeds", type=int, nargs="+", default=[0])
+ap.add_argument("--out", default=None)
+a = ap.parse_args()
+t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
+sc = crt.Scene.from_task(t, a.width, a.height)
+r = crt.Render(sc, a.spp, t.P_RR, t.light_sample_n)
+iv = crt.get_inverse_view_matrix(t.eye_pos, t.lookat, t.up)
+fov = crt.fov_to_radians(t.fov_y)
+cam = r._cam(t.eye_pos, iv, fov)
+total_rays = 0
+total_bad = 0
+for seed in a.seeds:
+    r.seed = seed
+    for rank in range(a.ranks):
+        slots = crt.shard_slots(a.width, a.height, rank, a.ranks)
+        res = {}
+        for name, trav in (("fast", crt.TRAVERSAL_FAST), ("ref", crt.TRAVERSAL_REFERENCE)):
+            r.traversal = trav
+            buf = np.zeros((slots, 3), dtype=np.uint8)
+            mean = np.zeros((slots, 3), dtype=np.float32)
+            prm = r._params(rank=rank, world=a.ranks, flags=capi.FLAG_TILED_OUTPUT, width=a.width, height=a.height)
+            st = capi.Stats()
+            t0 = time.perf_counter()
+            capi.check(capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), capi.ptr(mean), C.byref(st)), "crt_render")
+            res[name] = (mean, st.rays, time.perf_counter() - t0)
+        bad = int(np.count_nonzero(np.any(res["fast"][0].view(np.uint32) != res["ref"][0].view(np.uint32), axis=1)))
+        total_rays += res["fast"][1]
+        total_bad += bad
+        line = {"scene": a.scene, "size": [a.width, a.height, a.spp], "seed": seed, "rank": rank, "of": a.ranks, "rays": int(res["fast"][1]),
+                "rays_equal": bool(res["fast"][1] == res["ref"][1]), "slots_differ": bad, "fast_s": round(res["fast"][2], 2), "ref_s": round(res["ref"][2], 2)}
+        print(json.dumps(line), flush=True)
+        if a.out:
+            with open(a.out, "a") as f:
+                f.write(json.dumps(line) + "\n")
+print(json.dumps({"total_rays": int(total_rays), "slots_differ": total_bad}))
