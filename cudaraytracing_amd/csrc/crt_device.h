@@ -53,9 +53,12 @@ struct DevScene {
                              //   (e2.x a, e2.x b, e2.y a, e2.y b) (e2.z a, e2.z b, bits(index of a), bits(triangles of the leaf from a on))
                              // a leaf of n triangles owns ceil(n / 2) consecutive records
     int32_t root3_fast, root3_exact;
-    const float4* nodes4;    // the SAH tree collapsed to 4 children per node, 8 x float4 per node: children (0,1) as in nodes3
-                             // [0..2], children (2,3) [3..5], [6] = bits(ref 0..3) (>= 0: nodes4 index, < 0: leaf as in nodes3),
-                             // [7] padding; an empty slot has NaN boxes (no comparison of the slab test passes)
+    const float4* nodes4;    // the SAH tree collapsed to 4 children per node, 8 x float4 (128 B) per node, plane-major: [2a] = lo of axis
+                             // a of children 0..3, [2a + 1] = hi of axis a -- a ray loads the near plane [2a + (d_a < 0)] and the far
+                             // plane [2a + 1 - (d_a < 0)] of each axis, which is hit_AABB's swap done by the address;
+                             // [6] = bits(ref 0..3) (>= 0: nodes4 index, < 0: leaf as in nodes3), [7] padding; an empty slot is the
+                             // inverted box (lo = +inf, hi = -inf: entered at +inf, left at -inf for every direction).
+                             // (-DCRT_NODE_SIGNSEL=0: the round-1 layout, child pairs as in nodes3, NaN boxes for empty slots)
     int32_t root4;           // root of the 4-wide tree (a leaf ref if the scene is a single leaf)
     const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
 };

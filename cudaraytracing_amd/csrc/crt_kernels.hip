@@ -744,7 +744,8 @@ __device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint3
     // (the same predicate as k_mega3's start_ray: a non-finite ORIGIN puts NaNs into the min / max form of the slab test too)
     const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
     const bool finite_o = absf(L.r.o.x) <= FLT_MAX && absf(L.r.o.y) <= FLT_MAX && absf(L.r.o.z) <= FLT_MAX;
-    L.ref = (MODE == 0 && finite_inv && finite_o) ? sc.root_fast : sc.root_exact;
+    const bool finite_d = absf(L.r.d.x) <= FLT_MAX && absf(L.r.d.y) <= FLT_MAX && absf(L.r.d.z) <= FLT_MAX; // (1/d != 0)
+    L.ref = (MODE == 0 && finite_inv && finite_o && finite_d) ? sc.root_fast : sc.root_exact;
     if (L.any_hit) {
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) return TR_IDLE;
@@ -1058,8 +1059,9 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     uint32_t flags = nr.flags & ~RF_SKIP;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
-    const bool finite_inv = finite3(inv.x, inv.y, inv.z); // a finite 1/d has a finite d
-    const bool finite = finite_inv & finite3(nr.o.x, nr.o.y, nr.o.z);
+    // (a finite 1/d has a nonzero d; a finite d keeps 1/d away from 0, whose products with an overflowed plane distance would be NaNs)
+    const bool finite_inv = finite3(inv.x, inv.y, inv.z);
+    const bool finite = finite_inv & finite3(nr.o.x, nr.o.y, nr.o.z) & finite3(nr.d.x, nr.d.y, nr.d.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
     // (MODE 0: a ray that is not RF_EXACT walks the 4-wide tree; finite implies finite_inv)
     const int ref = (MODE == 0 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
@@ -1398,6 +1400,32 @@ __device__ __forceinline__ void slab_pair_pruned(const float4 n0, const float4 n
     tr = ((er <= __builtin_fminf(xr + CRT_EPSILON, bound)) & (xr >= 0)) ? er : inf;
 }
 
+// Plane-major nodes (CRT_NODE_SIGNSEL): the four children's near planes and far planes of each axis arrive as one float4 each,
+// picked per ray by the sign of its direction -- hit_AABB's own swap (DeviceBVH.cuh:101-119) done by the load address instead
+// of by comparisons: t_enter = max of the three near distances, t_exit = min of the three far ones (no operand is a NaN for a
+// ray with finite origin and 1/d and a finite box: x>y?x:y and v_max3 / v_min3 are the same numbers).  An empty slot is the
+// inverted box (+inf, -inf): t_enter = +inf, t_exit = -inf for either sign.
+#ifndef CRT_NODE_SIGNSEL
+#define CRT_NODE_SIGNSEL 1
+#endif
+__device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
+                                                 const F3 o, const F3 inv, const float bound, float& t0, float& t1, float& t2, float& t3)
+{
+    const v2f nxa = (v2(nx.x, nx.y) - v2s(o.x)) * v2s(inv.x), nxb = (v2(nx.z, nx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f nya = (v2(ny.x, ny.y) - v2s(o.y)) * v2s(inv.y), nyb = (v2(ny.z, ny.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f nza = (v2(nz.x, nz.y) - v2s(o.z)) * v2s(inv.z), nzb = (v2(nz.z, nz.w) - v2s(o.z)) * v2s(inv.z);
+    const v2f fxa = (v2(fx.x, fx.y) - v2s(o.x)) * v2s(inv.x), fxb = (v2(fx.z, fx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f fya = (v2(fy.x, fy.y) - v2s(o.y)) * v2s(inv.y), fyb = (v2(fy.z, fy.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f fza = (v2(fz.x, fz.y) - v2s(o.z)) * v2s(inv.z), fzb = (v2(fz.z, fz.w) - v2s(o.z)) * v2s(inv.z);
+    const float e0 = fmax3(nxa.x, nya.x, nza.x), e1 = fmax3(nxa.y, nya.y, nza.y), e2 = fmax3(nxb.x, nyb.x, nzb.x), e3 = fmax3(nxb.y, nyb.y, nzb.y);
+    const float x0 = fmin3(fxa.x, fya.x, fza.x), x1 = fmin3(fxa.y, fya.y, fza.y), x2 = fmin3(fxb.x, fyb.x, fzb.x), x3 = fmin3(fxb.y, fyb.y, fzb.y);
+    const float inf = pinf();
+    t0 = ((e0 <= __builtin_fminf(x0 + CRT_EPSILON, bound)) & (x0 >= 0)) ? e0 : inf;
+    t1 = ((e1 <= __builtin_fminf(x1 + CRT_EPSILON, bound)) & (x1 >= 0)) ? e1 : inf;
+    t2 = ((e2 <= __builtin_fminf(x2 + CRT_EPSILON, bound)) & (x2 >= 0)) ? e2 : inf;
+    t3 = ((e3 <= __builtin_fminf(x3 + CRT_EPSILON, bound)) & (x3 >= 0)) ? e3 : inf;
+}
+
 // The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
 // the t > EPSILON filter of DeviceBVHNode::hit (DeviceBVH.cuh:37); lane .x = first triangle, .y = second.
 __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4 g4, const F3 o, const F3 d,
@@ -1455,6 +1483,34 @@ __device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint
     ref = en;
     return false;
 }
+// The same pop in two halves: the top LDS level is read when the step begins -- nothing a step pushes can land on it (pushes go to
+// levels >= sp) -- so that its latency hides behind the node / leaf gather instead of standing alone at the end of the step.
+#ifndef CRT_POP_AHEAD
+#define CRT_POP_AHEAD 1
+#endif
+template <class LDS>
+__device__ __forceinline__ int stack_top_ahead(LDS& S, const uint32_t id, const int sp)
+{
+    const int lv = sp - 1;
+    return S.stk[(lv >= 0 && lv < POOL_LV) ? lv : 0][id];
+}
+template <class LDS>
+__device__ __forceinline__ bool stack_pop_ahead(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref, const int top)
+{
+#if CRT_POP_AHEAD
+    if (sp == 0) return true;
+    sp--;
+    int en = top;
+    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
+        if (sp >= POOL_LV) en = M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g];
+    }
+    ref = en;
+    return false;
+#else
+    (void)top;
+    return stack_pop(S, M3, id, g, sp, ref);
+#endif
+}
 template <class LDS>
 __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref)
 {
@@ -1482,13 +1538,33 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
 #else
 #define CRT_SEC4(i, dep)
 #endif
+#if CRT_NODE_SIGNSEL
+    const char* nb = (const char*)sc.nodes4; // 32-bit byte offsets: scalar base + vector offset addressing
+    const uint32_t noff = (uint32_t)ref * 128u;
+    const uint32_t ox = noff + ((__float_as_uint(inv.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv.y) >> 27) & 16u),
+                   oz = noff + ((__float_as_uint(inv.z) >> 27) & 16u); // + 16: the ray runs towards -axis, its near plane is hi
+    const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
+    const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
+    const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
+    const float4 rf = *(const float4*)((nb + noff) + 96);
+#else
     const float4* nd = (const float4*)((const char*)sc.nodes4 + (uint32_t)ref * 128u); // 32-bit byte offset: scalar base + vector offset addressing
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
+#endif
+#if CRT_POP_AHEAD
+    const int top = stack_top_ahead(S, id, sp);
+#else
+    const int top = 0;
+#endif
     CRT_SEC4(2, a0.x + a1.x + a2.x + b0.x + b1.x + b2.x + rf.x)
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
+#if CRT_NODE_SIGNSEL
+    slab_quad_pruned(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3);
+#else
     slab_pair_pruned(a0, a1, a2, o, inv, bound, t0, t1);
     slab_pair_pruned(b0, b1, b2, o, inv, bound, t2, t3);
+#endif
 #ifdef CRT_STAMPS
     { // sensitivity probes (tools/diag_sens.sh): result-neutral extra divergent 16 B loads / dependent VALU per inner step
         float dbg_acc = 0.0f;
@@ -1521,7 +1597,7 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     CRT_SEC4(3, sp + r0)
 #undef CRT_SEC4
     if (c0) { ref = r0; return false; }
-    return stack_pop(S, M, id, g, sp, ref);
+    return stack_pop_ahead(S, M, id, g, sp, ref, top); // (no child was hit: nothing was pushed, the top is the one read above)
 }
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
@@ -1783,6 +1859,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float T = qa.w;
                 int tri = __float_as_int(qb.w);
                 int sp = (int)(qd & 0xffu);
+#if CRT_POP_AHEAD
+                const int top = stack_top_ahead(S, id, sp);
+#else
+                const int top = 0;
+#endif
                 const bool any_hit = (qd & RF_ANYHIT) != 0;
                 int best_leaf = tri - (int)((qd >> 8) & 0xffffu); // first triangle of the leaf that holds the best hit (-1 - 0 if none)
                 bool done = false;
@@ -1816,7 +1897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 }
                 if (STATS) tc.leaf++;
                 if (!any_hit && tri >= 0) qd |= RF_HASHIT;
-                if (!done) done = stack_pop(S, M3, id, g, sp, ref);
+                if (!done) done = stack_pop_ahead(S, M3, id, g, sp, ref, top);
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
@@ -2859,6 +2940,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             todo.push_back(Todo{root4, 0, 1});
             root4 = 0;
             const float qn_ = std::numeric_limits<float>::quiet_NaN();
+            (void)qn_;
             for (size_t t = 0; t < todo.size(); t++) {
                 const Todo cur = todo[t];
                 depth4 = std::max(depth4, cur.depth + 1);
@@ -2885,18 +2967,31 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                             nodes4.resize(nodes4.size() + 8);
                             todo.push_back(Todo{ch[i].ref, refs[i], cur.depth + 1});
                         } else refs[i] = ch[i].ref;
-                    } else { // empty slot: a box of NaNs fails every comparison of the slab test
+                    } else {
+#if CRT_NODE_SIGNSEL
+                        // empty slot: the inverted box (t_enter = +inf, t_exit = -inf whatever the signs of the direction)
+                        for (int a = 0; a < 3; a++) { lo[i][a] = std::numeric_limits<float>::infinity(); hi[i][a] = -std::numeric_limits<float>::infinity(); }
+#else
+                        // empty slot: a box of NaNs fails every comparison of the slab test
                         for (int a = 0; a < 3; a++) { lo[i][a] = qn_; hi[i][a] = qn_; }
+#endif
                         refs[i] = ~0x7ffffff0; // (never followed)
                     }
                 }
                 float4* o = &nodes4[(size_t)cur.slot * 8];
+#if CRT_NODE_SIGNSEL
+                for (int a = 0; a < 3; a++) { // plane-major: [2a] = lo of axis a of the four children, [2a + 1] = hi
+                    o[2 * a + 0] = make_float4(lo[0][a], lo[1][a], lo[2][a], lo[3][a]);
+                    o[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]);
+                }
+#else
                 for (int pr = 0; pr < 2; pr++) { // children (0,1) then (2,3), pair-packed like nodes3
                     const int i = 2 * pr, j = i + 1;
                     o[pr * 3 + 0] = make_float4(lo[i][0], lo[j][0], lo[i][1], lo[j][1]);
                     o[pr * 3 + 1] = make_float4(lo[i][2], lo[j][2], hi[i][0], hi[j][0]);
                     o[pr * 3 + 2] = make_float4(hi[i][1], hi[j][1], hi[i][2], hi[j][2]);
                 }
+#endif
                 o[6] = make_float4(as_float(refs[0]), as_float(refs[1]), as_float(refs[2]), as_float(refs[3]));
                 o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
