@@ -411,3 +411,28 @@ def test_the_c5_visibility_rays_that_pruning_loses(bits, blocker):
         assert btri[0] == blocker
     finally:
         r.free()
+
+
+def test_raw_directions_with_infinite_components():
+    """A direction with an infinite component has 1/d = 0 (finite!): (plane - o) * 0 is 0, or NaN once plane - o overflows.  Such rays
+    must take the reference-arithmetic path (start_ray's predicate asks for a finite direction as well), so FAST and REFERENCE agree
+    on them bit for bit.  Only reachable through CRT_INTERSECT_RAW_DIRECTIONS: a Ray's own direction is normalised."""
+    name = "cornell-box"
+    t = util.task(name)
+    r = crt.Render(util.host_scene(name), 1, t.P_RR, t.light_sample_n)
+    try:
+        rng = np.random.RandomState(3)
+        n = 4096
+        o = (rng.rand(n, 3).astype(np.float32) - 0.5) * 600 + np.array([278, 273, 0], dtype=np.float32)
+        o[::7] *= np.float32(1e35)  # far out: plane - o is of the order of FLT_MAX / 10
+        d = rng.randn(n, 3).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        k = rng.randint(0, 3, n)
+        d[np.arange(n), k] = np.where(rng.rand(n) < 0.5, np.inf, -np.inf).astype(np.float32)
+        d[::5, (k[::5] + 1) % 3] = np.inf
+        RAW = crt.INTERSECT_RAW_DIRECTIONS
+        tri_r, t_r = r.intersect(o, d, traversal=crt.TRAVERSAL_REFERENCE | RAW)
+        tri_f, t_f = r.intersect(o, d, traversal=crt.TRAVERSAL_FAST | RAW)
+        assert np.array_equal(tri_r, tri_f) and np.array_equal(util.bits(t_r), util.bits(t_f))
+    finally:
+        r.free()
