@@ -173,3 +173,42 @@ def test_sampler_properties():
     out = np.array([0.3, 0.5, 0.8], dtype=np.float32)
     centre = O.sample_lobe(out, 0.2, 0.4, 0.5, 0.5)  # eta = 0: the lobe centre is out / |out|
     np.testing.assert_allclose(centre, out / np.linalg.norm(out), atol=2e-6)
+
+
+def test_ray_log_and_margin_histogram_diagnostics():
+    """The diagnostics behind tools/diff_fast_reference.py and tools/margin_hist.py: the ray log holds every ray of a render (count =
+    the `rays` statistic; closest-hit rays carry a NaN limit, next-event samples their t_to_light), replaying its rays through
+    orc_intersect gives the logged answers, the hit leaf's box entry never lies far behind the hit, and the margin histogram counts
+    the same rays."""
+    import ctypes as C
+    sc = util.oracle_scene("veach-mis")
+    t = util.task("veach-mis")
+    eye, iv, fov = util.camera("veach-mis")
+    L = O.lib()
+    L.orc_ray_log_begin.restype = None
+    L.orc_ray_log_end.restype = C.c_uint64
+    L.orc_ray_log_end.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_margin_hist.restype = None
+    L.orc_margin_hist.argtypes = [C.c_void_p]
+    L.orc_margin_hist(None)
+    L.orc_ray_log_begin()
+    _, _, _, st = sc.render(eye, iv, fov, 64, 48, 3, t.P_RR, t.light_sample_n, crop=(20, 20, 8, 8))
+    n = int(L.orc_ray_log_end(None, 0))
+    log = np.zeros((n, 10), dtype=np.float32)
+    L.orc_ray_log_end(log.ctypes.data_as(C.c_void_p), n)
+    hist = np.zeros(26, dtype=np.uint64)
+    L.orc_margin_hist(hist.ctypes.data_as(C.c_void_p))
+    assert n == st["rays"] == int(hist[25])
+    vis = ~np.isnan(log[:, 8])
+    assert int(vis.sum()) == st["shadow_rays"]
+    # replay (the oracle normalises a direction again: a Ray's own direction is a fixed point of that up to the last bit, so compare ids)
+    tri, tt, _ = sc.intersect(log[:, 0:3], log[:, 3:6])
+    same = tri == log[:, 7].astype(np.int32)
+    assert same.mean() > 0.999
+    hit = log[:, 7] >= 0
+    reach = np.abs(log[:, 0:3]).max(axis=1) + np.abs(log[:, 6])
+    with np.errstate(divide="ignore"):
+        steep = np.abs(1.0 / log[:, 3:6]).max(axis=1)
+    margin = (log[hit, 9] - log[hit, 6]) / (reach[hit] * steep[hit])
+    assert np.all(margin < 1.0e-4)  # (the pruning slack factor of CRT_TRAVERSAL_FAST; a ray beyond it would be a find, not a failure of the oracle)
+    assert int(hist[24]) <= int(hit.sum())
