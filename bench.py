@@ -363,6 +363,27 @@ def main_rank(args):
             all_traced = {"ms_per_step": round(dt_all * 1e3, 3), "mrays_per_sec": round(st_all["rays"] / dt_all / 1e6, 2),
                           "kernel_ms": round(st_all["kernel_ms"], 3)}
 
+        # ---- the same frame in CRT_TRAVERSAL_EXACT (the fast traversal without its pruning rule: provably the reference's frame,
+        #      DESIGN.md 4.3), timed and compared with the frame of the timed steps ----
+        exact_mode = None
+        if single and not multi and trav == crt.TRAVERSAL_FAST:
+            render.set_spp(args.spp)
+            render.traversal = crt.TRAVERSAL_FAST
+            fast_img, _ = step()
+            fast_img = fast_img.clone() if hasattr(fast_img, "clone") else np.array(fast_img)
+            render.traversal = crt.TRAVERSAL_EXACT
+            step()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            ex_img, st_ex = step()
+            torch.cuda.synchronize(device)
+            dt_ex = time.perf_counter() - c0
+            render.traversal = trav
+            same = bool((ex_img == fast_img).all()) if hasattr(ex_img, "all") else None
+            exact_mode = {"traversal": "exact", "ms_per_step": round(dt_ex * 1e3, 3), "kernel_ms": round(st_ex["kernel_ms"], 3),
+                          "mrays_per_sec": round(st_ex["rays"] / dt_ex / 1e6, 2), "rgb8_frame_equals_fast_frame": same,
+                          "rays_equal": bool(st_ex["rays"] == rays_local)}
+
         # ---- C3 (veach-mis 800x600 spp=1024: divergence stress) timed by the same run ----
         c3 = None
         if single and c2 and not multi and not args.no_c3:
@@ -393,12 +414,20 @@ def main_rank(args):
             torch.cuda.synchronize(device)
             dt3a = time.perf_counter() - c0
             r3.extra_flags = 0
+            r3.traversal = crt.TRAVERSAL_EXACT
+            step3()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            step3()
+            torch.cuda.synchronize(device)
+            dt3e = time.perf_counter() - c0
+            r3.traversal = crt.TRAVERSAL_FAST
             c3 = {"workload": "veach-mis 800x600 spp=1024 P_RR=%g light_sample_n=%d" % (float(t3.P_RR), t3.light_sample_n), "frames": 3,
                   "ms_per_frame": round(dt3 * 1e3, 3), "kernel_ms": round(float(np.mean(k3)), 3), "rays_per_frame": int(st3["rays"]),
                   "mrays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
                   "mrays_traced_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),
                   "untraced_frac": round(st3["rays_untraced"] / st3["rays"], 4),
-                  "all_rays_traced_ms": round(dt3a * 1e3, 3)}
+                  "all_rays_traced_ms": round(dt3a * 1e3, 3), "exact_mode_ms": round(dt3e * 1e3, 3)}
             p3, _ = load_pmc("c3")
             if p3 is not None:
                 c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3)
@@ -474,6 +503,7 @@ def main_rank(args):
             "rays_untraced_per_frame_rank0": int(untraced_local),
             "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
             "all_rays_traced": all_traced,
+            "exact_mode": exact_mode,
             "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
             "roofline": roofline,
             "fast_vs_reference": fast_vs_reference,

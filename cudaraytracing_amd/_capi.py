@@ -10,6 +10,7 @@ from . import build as _build
 CRT_OK = 0
 TRAVERSAL_FAST = 0
 TRAVERSAL_REFERENCE = 1
+TRAVERSAL_EXACT = 2
 FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4

@@ -60,6 +60,7 @@ struct DevScene {
                              // inverted box (lo = +inf, hi = -inf: entered at +inf, left at -inf for every direction).
                              // (-DCRT_NODE_SIGNSEL=0: the round-1 layout, child pairs as in nodes3, NaN boxes for empty slots)
     int32_t root4;           // root of the 4-wide tree (a leaf ref if the scene is a single leaf)
+    float coord_max;         // largest |coordinate| of a box of the 4-wide tree, +inf if one is not finite (start_ray: which rays may walk it)
     const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
 };
 

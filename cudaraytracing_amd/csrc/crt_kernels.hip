@@ -735,9 +735,9 @@ __device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint3
     L.nx = L.r.d.x < 0; L.ny = L.r.d.y < 0; L.nz = L.r.d.z < 0;
     L.t_limit = t_limit;
     // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
-    L.any_hit = MODE == 0 && kind == RAY_SHADOW;
+    L.any_hit = MODE != 1 && kind == RAY_SHADOW;
     L.best_t = FLT_MAX; L.best_tri = -1; L.best_leaf = -1;
-    L.bound = FLT_MAX;
+    L.bound = pinf(); // (no bound: a box entered at +inf is still a box the reference enters)
     L.sp = 0;
     // rays with a zero / denormal direction component (inv_dir not finite) can put NaNs into the
     // slab test; they walk the reference topology, whose box tests are the reference's own (crt_accel.h)
@@ -745,11 +745,11 @@ __device__ __forceinline__ int trav_begin(const DevScene& sc, TravLane& L, uint3
     const bool finite_inv = absf(L.r.inv.x) <= FLT_MAX && absf(L.r.inv.y) <= FLT_MAX && absf(L.r.inv.z) <= FLT_MAX;
     const bool finite_o = absf(L.r.o.x) <= FLT_MAX && absf(L.r.o.y) <= FLT_MAX && absf(L.r.o.z) <= FLT_MAX;
     const bool finite_d = absf(L.r.d.x) <= FLT_MAX && absf(L.r.d.y) <= FLT_MAX && absf(L.r.d.z) <= FLT_MAX; // (1/d != 0)
-    L.ref = (MODE == 0 && finite_inv && finite_o && finite_d) ? sc.root_fast : sc.root_exact;
+    L.ref = (MODE != 1 && finite_inv && finite_o && finite_d) ? sc.root_fast : sc.root_exact;
     if (L.any_hit) {
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         if (!(L.t_limit == L.t_limit) || L.t_limit == -pinf()) return TR_IDLE;
-        L.bound = prune_bound(L.t_limit, L.r.o, L.r.inv);
+        if (MODE == 0) L.bound = prune_bound(L.t_limit, L.r.o, L.r.inv); // (MODE 2, CRT_TRAVERSAL_EXACT: ordered and any-hit, never pruned)
     }
     return L.ref >= 0 ? TR_INNER : TR_LEAF;
 }
@@ -1059,15 +1059,19 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
     uint32_t flags = nr.flags & ~RF_SKIP;
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
-    // (a finite 1/d has a nonzero d; a finite d keeps 1/d away from 0, whose products with an overflowed plane distance would be NaNs)
-    const bool finite_inv = finite3(inv.x, inv.y, inv.z);
-    const bool finite = finite_inv & finite3(nr.o.x, nr.o.y, nr.o.z) & finite3(nr.d.x, nr.d.y, nr.d.z);
+    // The 4-wide step (slab_quad_pruned) needs every plane distance (plane - o) * (1/d) of the tree to be FINITE: then no operand of
+    // its v_max3 / v_min3 is a NaN, "+inf" can only mean "missed", and "no bound" can be any value >= FLT_MAX.  |plane - o| <=
+    // coord_max + max |o|, so a product of that with max |1/d| at or below 2^126 cannot overflow (two roundings of 2^-24 on the way);
+    // the comparison is false for a NaN anywhere and for an infinite origin, 1/d or scene coordinate.  A finite d keeps 1/d away from 0.
+    const float max_o = __builtin_elementwise_maximum(__builtin_elementwise_maximum(absf(nr.o.x), absf(nr.o.y)), absf(nr.o.z));
+    const float max_inv = __builtin_elementwise_maximum(__builtin_elementwise_maximum(absf(inv.x), absf(inv.y)), absf(inv.z));
+    const bool finite = ((sc.coord_max + max_o) * max_inv <= 0x1p126f) & finite3(nr.d.x, nr.d.y, nr.d.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
-    // (MODE 0: a ray that is not RF_EXACT walks the 4-wide tree; finite implies finite_inv)
-    const int ref = (MODE == 0 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
+    // (MODE 0 / 2: a ray that is not RF_EXACT walks the 4-wide tree)
+    const int ref = (MODE != 1 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
     bool answered = false;
     float T = FLT_MAX;
-    if (MODE == 0 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
+    if (MODE != 1 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
         flags |= RF_ANYHIT;
         T = nr.tl;
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
@@ -1091,7 +1095,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, u
 template <int MODE>
 __device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
 {
-    if (MODE == 0) return tri >= 0 || tl - FLT_MAX > CRT_EPSILON;
+    if (MODE != 1) return tri >= 0 || tl - FLT_MAX > CRT_EPSILON;
     return tl - T > CRT_EPSILON;
 }
 
@@ -1238,7 +1242,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     for (bool first = true;; first = false) {
         if (first) setup_shadow_lg(P, s, f3(m0.x, m0.y, m0.z), lg_next); // (s.q == q_next: the light entry is already here)
         else setup_shadow(P, tb, s, f3(m0.x, m0.y, m0.z));
-        skip = MODE == 0 && !trace_all && (s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f);
+        skip = MODE != 1 && !trace_all && (s.c.x == 0.0f && s.c.y == 0.0f && s.c.z == 0.0f);
         if (!skip) break;
         cnt.untraced++;
         if (__popcll(__builtin_amdgcn_ballot_w64(true)) < LA_LOOP_MIN) break; // (the lanes still in the loop are the ones that skip)
@@ -1803,10 +1807,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #endif
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
-#ifdef CRT_VIS_NOPRUNE
-                const float bound = ((qd & RF_HASHIT) && !(qd & RF_ANYHIT)) ? prune_bound(qa.w, o, inv) : FLT_MAX;
+                // (MODE 2 = CRT_TRAVERSAL_EXACT: the same traversal without this bound; +inf = no bound -- a box entered at +inf is still
+                // a box the reference enters, which matters to the reference-arithmetic step of the rays with non-finite operands)
+#if defined(CRT_VIS_NOPRUNE) /* measurement only: visibility rays unpruned */
+                const float bound = (MODE == 0 && (qd & RF_HASHIT) && !(qd & RF_ANYHIT)) ? prune_bound(qa.w, o, inv) : pinf();
 #else
-                const float bound = (qd & (RF_ANYHIT | RF_HASHIT)) ? prune_bound(qa.w, o, inv) : FLT_MAX;
+                const float bound = (MODE == 0 && (qd & (RF_ANYHIT | RF_HASHIT))) ? prune_bound(qa.w, o, inv) : pinf();
 #endif
                 bool done = false;
                 if (MODE == 1) {
@@ -2440,7 +2446,7 @@ struct TraceSetup {
     uint32_t blocks;
 };
 // Everything a k_trace launch over `pool` needs (grid sized to the device's residency: the kernel is persistent).
-TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, bool want_stats, int half = 0, int n_halves = 1)
+TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, uint32_t traversal, bool want_stats, int half = 0, int n_halves = 1)
 {
     TraceSetup S;
     std::memset(&S.T, 0, sizeof(S.T));
@@ -2454,8 +2460,9 @@ TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, boo
     const int lds_cap = (int)std::min<uint32_t>((uint32_t)sc->stack_cap, std::max(2u, env_u32("CRT_STACK_LDS", 8)));
     T.stack_cap = lds_cap;
     S.lds = (size_t)lds_cap * 256 * sizeof(int2);
-    S.mode_id = reference ? (want_stats ? 3 : 2) : (want_stats ? 1 : 0);
-    int per_cu = S.mode_id == 3 ? trace_blocks_per_cu<1, true>(S.lds) : S.mode_id == 2 ? trace_blocks_per_cu<1, false>(S.lds)
+    S.mode_id = (traversal == CRT_TRAVERSAL_REFERENCE ? 2 : traversal == CRT_TRAVERSAL_EXACT ? 4 : 0) + (want_stats ? 1 : 0);
+    int per_cu = S.mode_id == 5 ? trace_blocks_per_cu<2, true>(S.lds) : S.mode_id == 4 ? trace_blocks_per_cu<2, false>(S.lds)
+               : S.mode_id == 3 ? trace_blocks_per_cu<1, true>(S.lds) : S.mode_id == 2 ? trace_blocks_per_cu<1, false>(S.lds)
                : S.mode_id == 1 ? trace_blocks_per_cu<0, true>(S.lds) : trace_blocks_per_cu<0, false>(S.lds);
     // with two pool halves in flight leave room for the other half's k_logic blocks
     const uint32_t dflt_per_cu = n_halves > 1 ? 3u : 64u; // measured best on MI355X (C2): 3 trace blocks + logic blocks per CU
@@ -2470,7 +2477,9 @@ TraceSetup make_trace_setup(crt_scene* sc, const Pool& pool, bool reference, boo
 void launch_trace_pass(crt_scene* sc, const TraceSetup& S, hipStream_t st)
 {
     HIP_CHECK(hipMemsetAsync(S.T.slot_next, 0, (size_t)SLOT_SHARDS * SLOT_STRIDE * sizeof(unsigned int), st));
-    if (S.mode_id == 3) launch_trace<1, true>(S.T, S.blocks, S.lds, st);
+    if (S.mode_id == 5) launch_trace<2, true>(S.T, S.blocks, S.lds, st);
+    else if (S.mode_id == 4) launch_trace<2, false>(S.T, S.blocks, S.lds, st);
+    else if (S.mode_id == 3) launch_trace<1, true>(S.T, S.blocks, S.lds, st);
     else if (S.mode_id == 2) launch_trace<1, false>(S.T, S.blocks, S.lds, st);
     else if (S.mode_id == 1) launch_trace<0, true>(S.T, S.blocks, S.lds, st);
     else launch_trace<0, false>(S.T, S.blocks, S.lds, st);
@@ -2490,7 +2499,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
     if (prm->world == 0 || prm->rank >= prm->world) return fail(CRT_ERR_INVALID_ARG, "crt_render: need rank < world");
     if (prm->light_sample_n < 0 || prm->light_sample_n > 4096) return fail(CRT_ERR_INVALID_ARG, "crt_render: light_sample_n must be in [0, 4096]");
     if ((uint64_t)prm->width * prm->height > 0xffffffffull) return fail(CRT_ERR_UNSUPPORTED, "crt_render: more than 2^32 pixels");
-    if (prm->traversal != CRT_TRAVERSAL_FAST && prm->traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_render: unknown traversal mode");
+    if (prm->traversal != CRT_TRAVERSAL_FAST && prm->traversal != CRT_TRAVERSAL_REFERENCE && prm->traversal != CRT_TRAVERSAL_EXACT)
+        return fail(CRT_ERR_INVALID_ARG, "crt_render: unknown traversal mode");
     const bool want_stats = (prm->flags & CRT_FLAG_STATS) != 0;
     const bool tiled = (prm->flags & CRT_FLAG_TILED_OUTPUT) != 0;
     if (prm->world > 1 && !tiled) return fail(CRT_ERR_INVALID_ARG, "crt_render: world > 1 needs CRT_FLAG_TILED_OUTPUT");
@@ -2529,8 +2539,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         if (pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
+            const bool exact = prm->traversal == CRT_TRAVERSAL_EXACT;
             const int lds_cap = POOL_LV;
-            const int mode_id = (reference ? 2 : 0) + (want_stats ? 1 : 0);
+            const int mode_id = (reference ? 2 : exact ? 4 : 0) + (want_stats ? 1 : 0);
             const uint32_t pool_p = (uint32_t)POOL3_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
@@ -2542,7 +2553,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, false>, 64, 0)
                                  : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, true>, 64, 0)
                                  : mode_id == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, false>, 64, 0)
-                                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, true>, 64, 0);
+                                 : mode_id == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, true>, 64, 0)
+                                 : mode_id == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<2, false>, 64, 0)
+                                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<2, true>, 64, 0);
                     if (e != hipSuccess || *n < 1) *n = 1;
                 };
                 q3(&per_cu);
@@ -2606,7 +2619,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     else if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
                     else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
-                    else hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 3) hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    else if (mode_id == 4) hipLaunchKernelGGL((k_mega3<2, false>), dim3(blocks), dim3(64), 0, st, M3);
+                    else hipLaunchKernelGGL((k_mega3<2, true>), dim3(blocks), dim3(64), 0, st, M3);
                 }
                 HIP_CHECK(hipGetLastError());
                 if (s0 + ns >= s_end) HIP_CHECK(hipEventRecord(sc->ev_k1, st));
@@ -2691,7 +2706,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
 
         TraceSetup TS[2];
         LParams PH[2];
-        for (int h = 0; h < n_halves; h++) TS[h] = make_trace_setup(sc, pools[h], prm->traversal == CRT_TRAVERSAL_REFERENCE, want_stats, h, n_halves);
+        for (int h = 0; h < n_halves; h++) TS[h] = make_trace_setup(sc, pools[h], prm->traversal, want_stats, h, n_halves);
 
         AParams A;
         std::memset(&A, 0, sizeof(A));
@@ -2920,6 +2935,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         }
         // ---- 4-wide tree for the rays with finite operands: the SAH tree collapsed (crt_device.h, nodes4) ----
         std::vector<float4> nodes4;
+        float coord_max = 0.0f; // largest |coordinate| of a box of the 4-wide tree (+inf if any is not finite): start_ray's overflow test
         int32_t root4 = ref3(root_fast);
         int depth4 = 1;
         if (root4 >= 0) {
@@ -2978,6 +2994,11 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                         refs[i] = ~0x7ffffff0; // (never followed)
                     }
                 }
+                for (int i = 0; i < (int)ch.size() && i < 4; i++)
+                    for (int a = 0; a < 3; a++) {
+                        const float m = std::max(std::fabs(lo[i][a]), std::fabs(hi[i][a]));
+                        coord_max = (m <= FLT_MAX && coord_max <= FLT_MAX) ? std::max(coord_max, m) : std::numeric_limits<float>::infinity();
+                    }
                 float4* o = &nodes4[(size_t)cur.slot * 8];
 #if CRT_NODE_SIGNSEL
                 for (int a = 0; a < 3; a++) { // plane-major: [2a] = lo of axis a of the four children, [2a + 1] = hi
@@ -3000,6 +3021,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->nodes4.upload(nodes4);
         sc->dev.nodes4 = sc->nodes4.p;
         sc->dev.root4 = root4;
+        sc->dev.coord_max = coord_max;
         sc->depth4 = depth4;
         sc->accel.n_nodes4 = (uint32_t)(nodes4.size() / 8); sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
         std::vector<float4> tri_nm(d->n_tris);
@@ -3193,7 +3215,8 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
     const bool force_exact = (traversal & CRT_INTERSECT_FORCE_EXACT) != 0;
     const bool any_hit = (traversal & CRT_INTERSECT_VISIBILITY) != 0;
     traversal &= ~(uint32_t)(CRT_INTERSECT_RAW_DIRECTIONS | CRT_INTERSECT_FORCE_EXACT | CRT_INTERSECT_VISIBILITY);
-    if (traversal != CRT_TRAVERSAL_FAST && traversal != CRT_TRAVERSAL_REFERENCE) return fail(CRT_ERR_INVALID_ARG, "crt_intersect: unknown traversal mode");
+    if (traversal != CRT_TRAVERSAL_FAST && traversal != CRT_TRAVERSAL_REFERENCE && traversal != CRT_TRAVERSAL_EXACT)
+        return fail(CRT_ERR_INVALID_ARG, "crt_intersect: unknown traversal mode");
     if (n == 0) return CRT_OK;
     try {
         HIP_CHECK(hipSetDevice(sc->device));
@@ -3222,7 +3245,9 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             // the rays walk the traversal phases of the render kernel itself (k_mega3 in query form: work item = ray)
             const bool reference = traversal == CRT_TRAVERSAL_REFERENCE;
             int per_cu = 1;
+            const bool exact = traversal == CRT_TRAVERSAL_EXACT;
             if ((reference ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<1, false, false, true>, 64, 0)
+                 : exact   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<2, false, false, true>, 64, 0)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<0, false, false, true>, 64, 0)) != hipSuccess || per_cu < 1) per_cu = 1;
             const uint32_t pool_p = (uint32_t)POOL3_P;
             const uint32_t blocks = std::min<uint32_t>((n + pool_p - 1) / pool_p, (uint32_t)(sc->n_cus * per_cu));
@@ -3244,6 +3269,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             M3.force_exact = force_exact ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), nullptr));
             if (reference) hipLaunchKernelGGL((k_mega3<1, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
+            else if (exact) hipLaunchKernelGGL((k_mega3<2, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
             else hipLaunchKernelGGL((k_mega3<0, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipDeviceSynchronize());
@@ -3256,7 +3282,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             }
             return CRT_OK;
         }
-        TraceSetup TS = make_trace_setup(sc, pool, traversal == CRT_TRAVERSAL_REFERENCE, false);
+        TraceSetup TS = make_trace_setup(sc, pool, traversal, false);
         launch_trace_pass(sc, TS, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());

@@ -33,7 +33,7 @@ def _load(obj, mtl, thresh, w=48, h=36):
 def _check_rays(r, osc, o, d):
     otri, ot, _ = osc.intersect(o, d)
     out = {}
-    for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+    for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
         tri, t = r.intersect(o, d, traversal=mode)
         out[mode] = (tri, t)
         bad = np.nonzero((tri != otri) | (util.bits(t) != util.bits(ot)))[0]
@@ -139,7 +139,7 @@ def test_sliver_triangles(tmp_path, thresh):
     r.seed = 9
     try:
         orgb, omean, _, st = osc.render(eye, iv, fov, 64, 48, 2, 0.6, 2, seed=9)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), mode
@@ -181,7 +181,7 @@ def test_scene_far_from_the_origin(tmp_path, offset):
     r.seed = 5
     try:
         orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (offset, mode)
@@ -236,7 +236,7 @@ def test_fallbacks_to_the_wavefront_pipeline(tmp_path, monkeypatch, hook, value)
         r.run_view(eye, iv, fov)
         assert r.stats["kernel_launches"] == 1  # k_mega3: one launch per frame
         monkeypatch.setenv(hook, value)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert r.stats["kernel_launches"] > 1, hook  # rounds of k_logic + k_trace
@@ -272,7 +272,7 @@ def test_extreme_scales_on_the_wavefront_pipeline(tmp_path, monkeypatch, scale):
     r.seed = 5
     try:
         orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (scale, mode)
@@ -320,7 +320,8 @@ def test_the_c3_ray_that_the_old_pruning_bound_lost():
         # see the same float direction
         otri, ot, _ = osc.intersect(o, d)
         seen = set()
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT, crt.TRAVERSAL_EXACT,
+                     crt.TRAVERSAL_EXACT | crt.INTERSECT_FORCE_EXACT):
             tri, tt = r.intersect(o, d, traversal=mode)
             bad = np.nonzero((tri != otri) | (util.bits(tt) != util.bits(ot)))[0]
             assert bad.size == 0, (mode, bad[:5], tri[bad[:5]], otri[bad[:5]])
@@ -365,7 +366,8 @@ def test_visibility_queries(name):
         lim[:64] = np.tile(np.array([0.0, -1.0, np.inf, -np.inf, np.nan, 3.0e38, 1.0e-5, 2.0e-5], dtype=np.float32), 8)
         ob = _oracle_blocked(osc, o, d, lim)
         assert 0.2 < ob.mean() < 0.95  # both answers are well represented
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT, crt.TRAVERSAL_EXACT,
+                     crt.TRAVERSAL_EXACT | crt.INTERSECT_FORCE_EXACT):
             blk, tri = r.blocked(o, d, lim, traversal=mode)
             bad = np.nonzero(blk != ob)[0]
             assert bad.size == 0, (mode, bad[:8], lim[bad[:8]])
@@ -402,6 +404,10 @@ def test_the_c5_visibility_rays_that_pruning_loses(bits, blocker):
         assert tri[0] == blocker and lim[0] - tt[0] > np.float32(0.00001)
         blk, btri = r.blocked(o, d, lim, traversal=crt.TRAVERSAL_REFERENCE | RAW)
         assert blk[0] and btri[0] == blocker
+        # CRT_TRAVERSAL_EXACT -- the same traversal without the pruning rule -- must block it too, on both of its arithmetic paths
+        for mode in (crt.TRAVERSAL_EXACT, crt.TRAVERSAL_EXACT | crt.INTERSECT_FORCE_EXACT):
+            blk, btri = r.blocked(o, d, lim, traversal=mode | RAW)
+            assert blk[0] and btri[0] >= 0, mode
         # as a closest-hit query FAST finds the triangle (nothing nearer sets a bound before its box is reached)
         tri_f, tt_f = r.intersect(o, d, traversal=crt.TRAVERSAL_FAST | RAW)
         assert tri_f[0] == blocker and util.bits(tt_f)[0] == util.bits(tt)[0]
@@ -432,7 +438,8 @@ def test_raw_directions_with_infinite_components():
         d[::5, (k[::5] + 1) % 3] = np.inf
         RAW = crt.INTERSECT_RAW_DIRECTIONS
         tri_r, t_r = r.intersect(o, d, traversal=crt.TRAVERSAL_REFERENCE | RAW)
-        tri_f, t_f = r.intersect(o, d, traversal=crt.TRAVERSAL_FAST | RAW)
-        assert np.array_equal(tri_r, tri_f) and np.array_equal(util.bits(t_r), util.bits(t_f))
+        for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
+            tri_f, t_f = r.intersect(o, d, traversal=mode | RAW)
+            assert np.array_equal(tri_r, tri_f) and np.array_equal(util.bits(t_r), util.bits(t_f)), mode
     finally:
         r.free()

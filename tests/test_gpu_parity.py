@@ -86,7 +86,7 @@ def test_device_philox_matches_oracle_and_kat():
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
-@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST])
+@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT])
 def test_intersect_matches_oracle(renders, name, mode):
     o, d = util.random_rays(name, 4096, seed=11)
     tri, t = renders[name].intersect(o, d, traversal=mode)
@@ -101,7 +101,7 @@ CROPS = {"cornell-box": [(368, 268, 64, 48), (0, 0, 32, 24), (768, 576, 32, 24),
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
-@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST])
+@pytest.mark.parametrize("mode", [crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT])
 def test_render_crops_match_oracle(renders, name, mode):
     """800x600 at the scene's own config (C1 for cornell): crops against the oracle."""
     t = util.task(name)
@@ -139,11 +139,17 @@ def test_small_full_frame_matches_oracle_with_counters(renders, name):
     assert np.array_equal(rgb, orgb)
     for k in ("paths", "rays", "shadow_rays", "probe_rays", "inner_pops", "leaf_pops", "tri_tests", "hits"):
         assert r.stats[k] == st[k], k
-    r.traversal = crt.TRAVERSAL_FAST
-    rgb2 = r.run_view(eye, iv, fov, width=w, height=h)
-    assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
-    assert np.array_equal(rgb2, orgb)
-    assert r.stats["rays"] == st["rays"]
+    for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
+        r.traversal = mode
+        rgb2 = r.run_view(eye, iv, fov, stats=True, width=w, height=h)
+        assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean))
+        assert np.array_equal(rgb2, orgb)
+        assert r.stats["rays"] == st["rays"]
+        if mode == crt.TRAVERSAL_EXACT:
+            exact_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
+        else:
+            fast_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
+    assert exact_visits[0] >= fast_visits[0] and exact_visits[1] >= fast_visits[1]  # pruning only ever removes visits
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
@@ -155,9 +161,12 @@ def test_fast_equals_reference_full_frame(renders, name):
     r.traversal = crt.TRAVERSAL_REFERENCE
     r.run_view(eye, iv, fov)
     ref = r.mean_buffer.copy()
-    r.traversal = crt.TRAVERSAL_FAST
-    r.run_view(eye, iv, fov)
-    assert np.array_equal(util.bits(ref), util.bits(r.mean_buffer))
+    ref_rays = r.stats["rays"]
+    for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):  # (EXACT: the fast traversal without its pruning rule, provably identical)
+        r.traversal = mode
+        r.run_view(eye, iv, fov)
+        assert np.array_equal(util.bits(ref), util.bits(r.mean_buffer)), mode
+        assert r.stats["rays"] == ref_rays
 
 
 def test_seed_changes_image_and_is_reproducible(renders):
@@ -321,7 +330,7 @@ def _compare_room(tmp_path, thresh, lsn, p_rr, spp, specular=False, w=48, h=36, 
     r.extra_flags = extra_flags
     orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, p_rr, lsn, seed=seed)
     try:
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (thresh, lsn, p_rr, mode)
@@ -400,7 +409,7 @@ def test_triangle_soup_with_ties_and_degenerate_triangles(tmp_path, thresh):
     r.seed = 5
     orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
     try:
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), mode
@@ -411,7 +420,7 @@ def test_triangle_soup_with_ties_and_degenerate_triangles(tmp_path, thresh):
         rng = np.random.RandomState(1)
         o = np.tile(eye, (n, 1)).astype(np.float32)
         dd = (rng.uniform([1.5, 1.5, 9.0], [8.5, 8.5, 9.0], (n, 3)) - eye).astype(np.float32)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             tri, t = r.intersect(o, dd, traversal=mode)
             otri, ot, _ = osc.intersect(o, dd)
             assert np.array_equal(tri, otri) and np.array_equal(util.bits(t), util.bits(ot)), mode
@@ -444,7 +453,7 @@ def test_extreme_coordinate_scales(tmp_path, scale):
     r.seed = 5
     orgb, omean, _, st = osc.render(eye, iv, fov, w, h, spp, 0.6, 2, seed=5)
     try:
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
             r.traversal = mode
             rgb = r.run_view(eye, iv, fov)
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (scale, mode)

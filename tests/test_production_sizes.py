@@ -80,12 +80,14 @@ def test_c4_full_size_on_one_device_in_two_launches():
         one.extra_flags = 0
         # ... and the exhaustive REFERENCE traversal of the same 7.9 G rays (the pruning rule of FAST is not a theorem: the full-size
         # C3 frame once found a ray it lost, csrc/crt_trace.h)
-        one.traversal = crt.TRAVERSAL_REFERENCE
-        rgb_ref = one.run_view(eye, iv, fov, width=w, height=h)
-        one.traversal = crt.TRAVERSAL_FAST
-        assert one.stats["rays"] == st["rays"]
-        diff = np.argwhere(np.any(util.bits(one.mean_buffer) != util.bits(mean), axis=2))
-        assert diff.size == 0 and np.array_equal(rgb_ref, rgb), diff[:8]
+        # ... and of CRT_TRAVERSAL_EXACT, the fast traversal without the pruning rule (provably REFERENCE's frame)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_EXACT):
+            one.traversal = mode
+            rgb_ref = one.run_view(eye, iv, fov, width=w, height=h)
+            one.traversal = crt.TRAVERSAL_FAST
+            assert one.stats["rays"] == st["rays"]
+            diff = np.argwhere(np.any(util.bits(one.mean_buffer) != util.bits(mean), axis=2))
+            assert diff.size == 0 and np.array_equal(rgb_ref, rgb), (mode, diff[:8])
         for crop in _crops(w, h, 32, 24)[1:]:
             x0, y0, cw, ch = crop
             orgb, omean, _, _ = _oracle_crop(name, w, h, spp, crop)
@@ -137,11 +139,12 @@ def test_c5_shares_of_rank_0_and_rank_7_at_full_size():
         b0a, m0a, s0a = share(0, capi.FLAG_TRACE_ALL)
         assert s0a["rays"] == s0["rays"] and s0a["rays_untraced"] == 0 and s0["rays_untraced"] > 0
         assert np.array_equal(b0a, b0) and np.array_equal(util.bits(m0a), util.bits(m0))
-        one.traversal = crt.TRAVERSAL_REFERENCE   # the exhaustive traversal of the same 7.6 G rays
-        b0r, m0r, s0r = share(0)
-        one.traversal = crt.TRAVERSAL_FAST
-        diff = np.argwhere(np.any(util.bits(m0r) != util.bits(m0), axis=1))
-        assert s0r["rays"] == s0["rays"] and diff.size == 0 and np.array_equal(b0r, b0), diff[:8]
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_EXACT):   # the exhaustive / the unpruned traversal of the same 7.6 G rays
+            one.traversal = mode
+            b0r, m0r, s0r = share(0)
+            one.traversal = crt.TRAVERSAL_FAST
+            diff = np.argwhere(np.any(util.bits(m0r) != util.bits(m0), axis=1))
+            assert s0r["rays"] == s0["rays"] and diff.size == 0 and np.array_equal(b0r, b0), (mode, diff[:8])
         b7, m7, s7 = share(7)
         # rank 0: a tile in the middle of the plates; rank 7: the last tile of the frame
         for rank, buf, mean, tile in ((0, b0, m0, (ty // 2) * tx + tx // 2 - ((ty // 2) * tx + tx // 2) % 8), (7, b7, m7, tx * ty - 1)):
@@ -167,11 +170,11 @@ def test_c3_full_size():
         rgb = r.run_view(eye, iv, fov, width=w, height=h).copy()
         mean, st = r.mean_buffer.copy(), dict(r.stats)
         assert st["paths"] == w * h * spp and st["rays"] > 3 * 10 ** 9 and st["rays_untraced"] > 0.3 * st["rays"]
-        for trav, flags in ((crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0)):
+        for trav, flags in ((crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0), (crt.TRAVERSAL_EXACT, 0)):
             r.traversal, r.extra_flags = trav, flags
             rgb2 = r.run_view(eye, iv, fov, width=w, height=h)
             assert np.array_equal(rgb2, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean)), (trav, flags)
-            assert r.stats["rays"] == st["rays"] and r.stats["rays_untraced"] == 0
+            assert r.stats["rays"] == st["rays"] and r.stats["rays_untraced"] == (st["rays_untraced"] if trav == crt.TRAVERSAL_EXACT else 0)
         for crop in ((392, 300, 16, 12), (200, 140, 16, 12), (w - 16, h - 12, 16, 12)):
             x0, y0, cw, ch = crop
             orgb, omean, _, _ = _oracle_crop(name, w, h, spp, crop)

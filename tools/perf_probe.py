@@ -16,7 +16,7 @@ a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, a.width, a.height)
 r = crt.Render(sc, a.spp, t.P_RR, t.light_sample_n)
-r.traversal = crt.TRAVERSAL_FAST if a.traversal == "fast" else crt.TRAVERSAL_REFERENCE
+r.traversal = {"fast": crt.TRAVERSAL_FAST, "exact": crt.TRAVERSAL_EXACT, "reference": crt.TRAVERSAL_REFERENCE}[a.traversal]
 iv = crt.get_inverse_view_matrix(t.eye_pos, t.lookat, t.up)
 fov = crt.fov_to_radians(t.fov_y)
 for i in range(a.reps):
