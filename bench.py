@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--traversal", default="fast", choices=["fast", "reference"])
+    ap.add_argument("--traversal", default="fast", choices=["fast", "exact", "reference"])
     ap.add_argument("--engine", default="procs", choices=["procs", "multi"],
                     help="procs: one process per GPU, torch.distributed over RCCL; multi: one process, crt_multi_render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,7 +193,7 @@ def main_rank(args):
     eye = task.eye_pos
     inv_view = crt.get_inverse_view_matrix(task.eye_pos, task.lookat, task.up)
     fov = crt.fov_to_radians(task.fov_y)
-    trav = crt.TRAVERSAL_FAST if args.traversal == "fast" else crt.TRAVERSAL_REFERENCE
+    trav = {"fast": crt.TRAVERSAL_FAST, "exact": crt.TRAVERSAL_EXACT, "reference": crt.TRAVERSAL_REFERENCE}[args.traversal]
     mr = None
     if multi:
         devs = [0] * args.gpus if one_device else list(range(args.gpus))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Soak test of CRT_TRAVERSAL_FAST against the exhaustive CRT_TRAVERSAL_REFERENCE: renders the shards of a frame in both modes and
-counts the pixel slots whose float mean differs (expected: 0).  One line of JSON per shard."""
+"""Soak test of CRT_TRAVERSAL_FAST (or, --mode exact, of CRT_TRAVERSAL_EXACT) against the exhaustive CRT_TRAVERSAL_REFERENCE: renders the
+shards of a frame in both modes and counts the pixel slots whose float mean differs.  One line of JSON per shard."""
 import argparse, ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,8 @@ ap.add_argument("--spp", type=int, default=4096)
 ap.add_argument("--ranks", type=int, default=8)
 ap.add_argument("--seeds", type=int, nargs="+", default=[0])
 ap.add_argument("--out", default=None)
+ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
+ap.add_argument("--only", type=int, nargs="*", default=None, help="ranks to render (default: all)")
 a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, a.width, a.height)
@@ -27,10 +29,10 @@ total_rays = 0
 total_bad = 0
 for seed in a.seeds:
     r.seed = seed
-    for rank in range(a.ranks):
+    for rank in (a.only if a.only else range(a.ranks)):
         slots = crt.shard_slots(a.width, a.height, rank, a.ranks)
         res = {}
-        for name, trav in (("fast", crt.TRAVERSAL_FAST), ("ref", crt.TRAVERSAL_REFERENCE)):
+        for name, trav in (("fast", crt.TRAVERSAL_EXACT if a.mode == "exact" else crt.TRAVERSAL_FAST), ("ref", crt.TRAVERSAL_REFERENCE)):
             r.traversal = trav
             buf = np.zeros((slots, 3), dtype=np.uint8)
             mean = np.zeros((slots, 3), dtype=np.float32)
@@ -42,7 +44,7 @@ for seed in a.seeds:
         bad = int(np.count_nonzero(np.any(res["fast"][0].view(np.uint32) != res["ref"][0].view(np.uint32), axis=1)))
         total_rays += res["fast"][1]
         total_bad += bad
-        line = {"scene": a.scene, "size": [a.width, a.height, a.spp], "seed": seed, "rank": rank, "of": a.ranks, "rays": int(res["fast"][1]),
+        line = {"mode": a.mode, "scene": a.scene, "size": [a.width, a.height, a.spp], "seed": seed, "rank": rank, "of": a.ranks, "rays": int(res["fast"][1]),
                 "rays_equal": bool(res["fast"][1] == res["ref"][1]), "slots_differ": bad, "fast_s": round(res["fast"][2], 2), "ref_s": round(res["ref"][2], 2)}
         print(json.dumps(line), flush=True)
         if a.out:
