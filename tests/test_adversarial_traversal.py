@@ -245,7 +245,14 @@ def test_fallbacks_to_the_wavefront_pipeline(tmp_path, monkeypatch, hook, value)
         rng = np.random.RandomState(4)
         o = rng.uniform(0.5, 9.5, (4096, 3)).astype(np.float32)
         d = rng.normal(size=(4096, 3)).astype(np.float32)
-        _check_rays(r, osc, o, d)  # crt_intersect follows the same choice (k_trace)
+        otri, ot = _check_rays(r, osc, o, d)  # crt_intersect follows the same choice (k_trace)
+        # ... and so do the visibility queries: limits on both sides of the closest hit and the degenerate ones
+        lim = np.where(ot < np.float32(3.0e38), ot, np.float32(5.0)) * rng.choice(np.array([0.5, 0.99999, 1.0, 1.00001, 1.5], dtype=np.float32), 4096)
+        lim[:40] = np.tile(np.array([0.0, -1.0, np.inf, -np.inf, np.nan, 3.0e38, 1.0e-5, 2.0e-5], dtype=np.float32), 5)
+        ob = _oracle_blocked(osc, o, d, lim)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
+            blk, _ = r.blocked(o, d, lim, traversal=mode)
+            assert np.array_equal(blk, ob), (hook, mode, np.nonzero(blk != ob)[0][:8])
     finally:
         r.free()
 
