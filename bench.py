@@ -100,9 +100,28 @@ def spawn_ranks(args):
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
                     "CRT_BENCH_SPAWNED": "1"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # if one rank dies the others would wait in a collective until its time-out: end them (by their own PIDs) as soon as one fails
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = max(rc, abs(code))
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + 10.0
+                for q in live:
+                    try:
+                        q.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                live = []
+                break
     return rc
 
 
@@ -169,6 +188,9 @@ def main_rank(args):
     one_device = os.environ.get("CRT_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    n_dev = torch.cuda.device_count()
+    if (args.gpus if multi else local_rank + 1) > n_dev and not one_device:
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) (CRT_BENCH_ONE_DEVICE=1 rehearses the N > 1 path on one)" % (args.gpus, n_dev))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = None
