@@ -1,4 +1,5 @@
 #!/bin/bash
+set -o pipefail  # a crashed probe must stop the script (a GPU fault must never be followed by another GPU step)
 # Diagnostic: rebuilds libcrt.so with -DCRT_STAMPS on the GPU box and prints the per-phase cycle /
 # iteration / lane counters of k_mega3 (phase_cycles of crt_stats).  usage: tools/diag_phases.sh [spp] [scene]
 spp=${1:-64}; scene=${2:-cornell-box}

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -o pipefail  # a crashed probe must stop the script (a GPU fault must never be followed by another GPU step)
 # usage: tools/time_variant.sh "<flags>" ...   timing only (C2 and veach spp 256) of builds with extra compile flags; restores the default build
 trap 'unset CRT_EXTRA_CXXFLAGS; python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1' EXIT  # always leave the default build in the tree
 for flags in "$@"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -o pipefail  # a crashed probe must stop the script (a GPU fault must never be followed by another GPU step)
 # Builds libcrt.so with extra compile flags on the GPU box, runs the parity tests of the default pipeline and a timing probe.
 # usage: tools/try_variant.sh "<flags>" [spp]
 trap 'unset CRT_EXTRA_CXXFLAGS; python3 cudaraytracing_amd/build.py --force > /dev/null 2>&1' EXIT  # always leave the default build in the tree
