@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace crtaccel {
@@ -60,7 +61,10 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
     if (index_splits) *index_splits = 0;
     const int n = (int)prims.size();
     if (n == 1) { root_ref = prims[0].ref; return 1; }
-    const int NB = 32;
+    // (CRT_SAH_BINS: experiment hook of the HOST builder only -- the device builder has 32 bins, and the two are compared node for node)
+    const int NBMAX = 256;
+    int NB = 32;
+    if (const char* e_ = std::getenv("CRT_SAH_BINS")) NB = std::min(NBMAX, std::max(2, std::atoi(e_)));
     struct Task { int b, e, node, slot, depth; };
     // temporary tree in build order, renumbered breadth-first at the end
     struct Tmp { Box box[2]; int32_t child[2]; int depth; };
@@ -89,8 +93,8 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
         for (int a = 0; a < 3; a++) {
             float ext = chi[a] - clo[a];
             if (!(ext > 0.0f)) continue;
-            Box bb[NB];
-            int bc[NB];
+            Box bb[NBMAX];
+            int bc[NBMAX];
             for (int k = 0; k < NB; k++) { bb[k].reset(); bc[k] = 0; }
             const float scale = (float)NB / ext;
             for (int i = b; i < e; i++) {
@@ -99,8 +103,8 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
                 bb[k].grow(prims[i].box);
                 bc[k]++;
             }
-            double right_area[NB];
-            int right_cnt[NB];
+            double right_area[NBMAX];
+            int right_cnt[NBMAX];
             Box acc;
             acc.reset();
             int c = 0;
