@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdint>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -65,6 +66,8 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
     const int NBMAX = 256;
     int NB = 32;
     if (const char* e_ = std::getenv("CRT_SAH_BINS")) NB = std::min(NBMAX, std::max(2, std::atoi(e_)));
+    double cost_pow = 1.0; // (CRT_SAH_POW: experiment hook of the HOST builder only: leaf-count exponent of the split cost)
+    if (const char* e_ = std::getenv("CRT_SAH_POW")) cost_pow = std::atof(e_);
     struct Task { int b, e, node, slot, depth; };
     // temporary tree in build order, renumbered breadth-first at the end
     struct Tmp { Box box[2]; int32_t child[2]; int depth; };
@@ -116,6 +119,7 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
                 c += bc[k];
                 if (c == 0 || right_cnt[k + 1] == 0) continue;
                 double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+                if (cost_pow != 1.0) cost = acc.half_area() * std::pow((double)c, cost_pow) + right_area[k + 1] * std::pow((double)right_cnt[k + 1], cost_pow);
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = k; }
             }
         }
