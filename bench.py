@@ -112,8 +112,12 @@ def spawn_ranks(args):
             live.remove(p)
             if code != 0:
                 rc = max(rc, abs(code))
+                t_grace = time.time() + 5.0  # the others usually fail for the same reason a moment later: let them say so
+                while time.time() < t_grace and any(q.poll() is None for q in live):
+                    time.sleep(0.1)
                 for q in live:
-                    q.terminate()
+                    if q.poll() is None:
+                        q.terminate()
                 t_end = time.time() + 10.0
                 for q in live:
                     try:
