@@ -906,12 +906,11 @@ struct MParams {
 //     path belongs elsewhere (emitter found in LA, roulette stop in LB) parks it there without a ray.
 //   * 1/direction lives in the LDS record (64 B per ray: origin, direction, 1/direction, one distance,
 //     best triangle, node, flags, 3 stack levels, ring slots), so the inner step has no divisions;
-//   * inner nodes are stored as (left, right) PAIRS per coordinate, so that both child boxes go through
-//     v_pk_add_f32 / v_pk_mul_f32 together; rays whose origin, direction and 1/direction are all finite
-//     (all but a handful) finish the test with v_min / v_max / v_min3 / v_max3: for finite operands
-//     min(t_lo, t_hi) IS the reference's sign-selected entry distance (rounding is monotone), so the bits
-//     are the same; the others keep the reference formula with its NaN behaviour (DeviceBVH.cuh:97-121)
-//     and walk the reference topology;
+//   * the nodes of the 2-wide trees are stored as (left, right) PAIRS per coordinate, those of the 4-wide tree plane-major (four
+//     children per float4), so that child boxes go through v_pk_add_f32 / v_pk_mul_f32 two at a time; rays whose plane
+//     distances are all finite (start_ray; all but a handful) walk the 4-wide tree, whose near / far planes are picked by the
+//     load address (the reference's sign swap) and combined with v_max3 / v_min3; the others keep the reference formula
+//     with its NaN behaviour (DeviceBVH.cuh:97-121) and walk the reference topology;
 //   * the (<= 2) triangles of a leaf are one 80 B record, both Moeller-Trumbore tests run as one packed
 //     computation (same operations per triangle, two at a time).
 #define PH3_INNER 0
@@ -1525,10 +1524,10 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
     sp++;
 }
 
-// One step at a node of the 4-wide tree (rays with finite operands, CRT_TRAVERSAL_FAST): four child boxes as two packed pairs,
-// the nearest hit child next, the others pushed farthest first.  Which children are visited, and in
-// which order, does not change the result (crt_trace.h); the boxes and the test are the reference's (hit_AABB with minima /
-// maxima, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
+// One step at a node of the 4-wide tree (rays with finite operands, CRT_TRAVERSAL_FAST / _EXACT): the four child boxes from their
+// near and far planes (picked by the sign of the direction, the reference's own swap), the nearest hit child next, the others pushed
+// farthest first.  Which children are visited, and in which order, does not change the result (crt_trace.h); the boxes and the test
+// are the reference's (hit_AABB, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, class LDS>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
                                             const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu
