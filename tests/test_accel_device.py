@@ -104,3 +104,37 @@ def test_soup_with_duplicates_matches_the_oracle(tmp_path, monkeypatch):
     finally:
         dev.free()
         host.free()
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_collapse_by_dynamic_programming_against_the_greedy_one(name, monkeypatch):
+    """The 4-wide collapse minimises the summed area of the wide nodes (dynamic programming, csrc/crt_kernels.hip); the round-1 rule
+    (CRT_COLLAPSE=greedy: open the largest child until there are four) stays selectable.  Same frame either way (any tree over the
+    reference's leaves gives the same hits); the optimal collapse has no more nodes and no more inner steps on the frame."""
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    osc = util.oracle_scene(name)
+    monkeypatch.delenv("CRT_COLLAPSE", raising=False)
+    dp = crt.Render(util.host_scene(name), 2, t.P_RR, t.light_sample_n)
+    monkeypatch.setenv("CRT_COLLAPSE", "greedy")
+    gr = crt.Render(util.host_scene(name), 2, t.P_RR, t.light_sample_n)
+    monkeypatch.delenv("CRT_COLLAPSE", raising=False)
+    try:
+        a, b = dp.accel_info(), gr.accel_info()
+        assert a["n_leaves"] == b["n_leaves"] and a["n_nodes2"] == b["n_nodes2"] and a["n_nodes4"] <= b["n_nodes4"]
+        ra = dp.run_view(eye, iv, fov, stats=True, width=160, height=120).copy()
+        ma = dp.mean_buffer.copy()
+        rb = gr.run_view(eye, iv, fov, stats=True, width=160, height=120)
+        assert np.array_equal(ra, rb) and np.array_equal(util.bits(ma), util.bits(gr.mean_buffer))
+        orgb, omean, _, st = osc.render(eye, iv, fov, 160, 120, 2, t.P_RR, t.light_sample_n)
+        assert np.array_equal(ra, orgb) and np.array_equal(util.bits(ma), util.bits(omean))
+        assert dp.stats["rays"] == gr.stats["rays"] == st["rays"]
+        assert dp.stats["inner_pops"] <= gr.stats["inner_pops"]
+        # every leaf is reachable in both trees: the closest hits of random rays are the oracle's
+        o, d = util.random_rays(name, 4096, seed=3)
+        otri, ot, _ = osc.intersect(o, d)
+        for r in (dp, gr):
+            tri, tt = r.intersect(o, d, traversal=crt.TRAVERSAL_EXACT)
+            assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot))
+    finally:
+        dp.free(); gr.free()
