@@ -107,7 +107,7 @@ enum {
                                     lying in the plane of a triangle (det -> 0: unbounded error, and the reference has no determinant
                                     threshold).  MEASURED (tools/soak_fast_vs_reference.py, profiles/r02_soak_fast_vs_reference.jsonl): 2 rays in
                                     3.66e11 on full 1920x1080x4096 veach-mis frames (tessellated spheres; each changes one next-event sample:
-                                    the last bit of one pixel), 0 in 2.4e10 on full 3840x2160x256 cornell-box frames; a larger factor only thins
+                                    the last bit of one pixel), 0 in 3.4e11 on full 3840x2160x256 cornell-box frames; a larger factor only thins
                                     them out.  Bit-identical to REFERENCE on every frame and probe of the test-suite
                                     (tests/test_production_sizes.py, tests/test_adversarial_traversal.py -- two lost rays are kept there as
                                     known answers), and bench.py re-checks a slice of the benchmark frame against REFERENCE in every run.
