@@ -42,14 +42,37 @@ def built_flags():
 KERNEL_DEPS = ["crt_kernels.hip", "crt_device.h", "crt_trace.h", "crt_accel.h", "crt_accel_build.hip", "crt_detmath.h"]  # what the render kernels are made of
 
 
+def _code_only(text):
+    """C / C++ source without comments and with runs of white space collapsed: what the compiler sees, more or less -- so that
+    editing a comment does not invalidate the profiles stamped with source_hash()."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":                       # string / character literal: copied as it is
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash():
-    """SHA-256 over the sources of the render kernels (and of the host code that lays out what they walk) and the flag
-    string: stamps profiles (bench.py drops PMC numbers collected on other code)."""
+    """SHA-256 over the code (comments and white space aside) of the render kernels and of the host code that lays out what they
+    walk, and the flag string: stamps profiles (bench.py drops PMC numbers collected on other code)."""
     import hashlib
     h = hashlib.sha256()
     for d in sorted(KERNEL_DEPS):
-        with open(os.path.join(CSRC, d), "rb") as f:
-            h.update(d.encode() + b"\0" + f.read())
+        with open(os.path.join(CSRC, d), "r", encoding="utf-8", errors="replace") as f:
+            h.update(d.encode() + b"\0" + _code_only(f.read()).encode())
     h.update(flags_string().encode())
     return h.hexdigest()[:16]
 
