@@ -180,6 +180,121 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
     return max_depth;
 }
 
+// Insertion-based optimisation of a built tree (Bittner, Hapala, Havran 2013, simplified): every node in turn (largest first) is
+// taken out of the tree and put back where it adds the least surface area (its own new parent's area plus what it makes its new
+// ancestors grow by), found by a best-first search with the induced cost as lower bound.  The old position is among the candidates,
+// so the summed area of the inner nodes never grows.  Experiment hook (CRT_SAH_OPT=<passes>): the tree stays a tree over the same
+// leaves, so results cannot change.  Returns the new depth; nodes come back in breadth-first order, root = 0.
+inline int optimize_sah(std::vector<Node>& nodes, int passes)
+{
+    const int A = (int)nodes.size();
+    if (A < 3 || passes <= 0) {
+        // depth of the tree as it is
+        std::vector<int> dep(A, 1);
+        int md = A ? 2 : 1;
+        for (int q = 0; q < A; q++)
+            for (int s = 0; s < 2; s++) {
+                if (nodes[q].child[s] >= 0) dep[nodes[q].child[s]] = dep[q] + 1;
+                md = std::max(md, dep[q] + 1);
+            }
+        return md;
+    }
+    struct N { Box box; int parent, child[2]; int32_t leaf_ref; double area; };
+    std::vector<N> t((size_t)2 * A + 1);
+    int n_all = A;
+    for (int q = 0; q < A; q++) { t[q].parent = -1; t[q].leaf_ref = 0; }
+    for (int q = 0; q < A; q++)
+        for (int s = 0; s < 2; s++) {
+            const int32_t c = nodes[q].child[s];
+            int id;
+            if (c >= 0) id = c;
+            else { id = n_all++; t[id].child[0] = t[id].child[1] = -1; t[id].leaf_ref = c; }
+            t[q].child[s] = id;
+            t[id].parent = q;
+            t[id].box = nodes[q].box[s];
+            t[id].area = t[id].box.half_area();
+        }
+    t[0].box = nodes[0].box[0]; t[0].box.grow(nodes[0].box[1]); t[0].area = t[0].box.half_area();
+    int root = 0;
+    auto is_leaf = [&](int x) { return t[x].child[0] < 0; };
+    auto refit_up = [&](int x) {
+        for (; x >= 0; x = t[x].parent) {
+            Box b = t[t[x].child[0]].box;
+            b.grow(t[t[x].child[1]].box);
+            t[x].box = b;
+            t[x].area = b.half_area();
+        }
+    };
+    struct Cand { double ind; int x; };
+    auto cmp = [](const Cand& a, const Cand& b) { return a.ind > b.ind; };
+    std::vector<Cand> heap;
+    for (int pass = 0; pass < passes; pass++) {
+        std::vector<int> order;
+        for (int x = 0; x < n_all; x++)
+            if (x != root && t[x].parent != root) order.push_back(x);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a].area != t[b].area ? t[a].area > t[b].area : a < b; });
+        for (int x : order) {
+            const int P = t[x].parent;
+            if (P < 0 || P == root) continue; // (the tree above may have changed since the list was made)
+            const int S = t[P].child[0] == x ? t[P].child[1] : t[P].child[0];
+            const int G = t[P].parent;
+            // take x (and its parent node P) out: the sibling moves up
+            t[G].child[t[G].child[0] == P ? 0 : 1] = S;
+            t[S].parent = G;
+            refit_up(G);
+            // where does it cost least?
+            const Box bx = t[x].box;
+            const double ax = t[x].area;
+            double best = DBL_MAX;
+            int best_x = S;
+            heap.clear();
+            heap.push_back(Cand{0.0, root});
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                const Cand c = heap.back();
+                heap.pop_back();
+                if (c.ind + ax >= best) break; // the cheapest induced cost left cannot beat the best position any more
+                Box u = t[c.x].box;
+                u.grow(bx);
+                const double direct = u.half_area();
+                if (c.ind + direct < best) { best = c.ind + direct; best_x = c.x; }
+                if (!is_leaf(c.x)) {
+                    const double ind = c.ind + direct - t[c.x].area;
+                    if (ind + ax < best)
+                        for (int s2 = 0; s2 < 2; s2++) { heap.push_back(Cand{ind, t[c.x].child[s2]}); std::push_heap(heap.begin(), heap.end(), cmp); }
+                }
+            }
+            // P becomes the parent of (best_x, x) in best_x's place
+            const int Q = t[best_x].parent;
+            t[P].child[0] = best_x; t[P].child[1] = x;
+            t[P].parent = Q;
+            t[best_x].parent = P; t[x].parent = P;
+            if (Q >= 0) t[Q].child[t[Q].child[0] == best_x ? 0 : 1] = P;
+            else root = P;
+            refit_up(P);
+        }
+    }
+    // back to the breadth-first array of inner nodes
+    std::vector<int> order, index((size_t)n_all, -1), dep;
+    order.push_back(root); dep.push_back(1); index[root] = 0;
+    int md = 2;
+    for (size_t q = 0; q < order.size(); q++)
+        for (int s = 0; s < 2; s++) {
+            const int c = t[order[q]].child[s];
+            md = std::max(md, dep[q] + 1);
+            if (!is_leaf(c)) { index[c] = (int)order.size(); order.push_back(c); dep.push_back(dep[q] + 1); }
+        }
+    std::vector<Node> out(order.size());
+    for (size_t q = 0; q < order.size(); q++)
+        for (int s = 0; s < 2; s++) {
+            const int c = t[order[q]].child[s];
+            out[q].box[s] = t[c].box;
+            out[q].child[s] = is_leaf(c) ? t[c].leaf_ref : index[c];
+        }
+    nodes.swap(out);
+    return md;
+}
+
 // The same tree built on the current HIP device (crt_accel_build.hip): node for node the tree of build_sah, except where a range is
 // split "by index" (coinciding centroids).  Returns the depth, or -1 if the device build could not run (use build_sah then).
 int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t& root_ref, float* device_ms, uint32_t* index_splits = nullptr);

@@ -17,7 +17,8 @@ r.run_view(t.eye_pos, iv, fov, stats=True, want_mean=False)
 s = r.stats
 out = {"scene": a.scene, "CRT_COLLAPSE": os.environ.get("CRT_COLLAPSE", ""), "accel": r.accel_info(),
        "inner_per_ray": round(s["inner_pops"] / s["rays"], 3), "leaf_per_ray": round(s["leaf_pops"] / s["rays"], 3),
-       "tests_per_ray": round(s["tri_tests"] / s["rays"], 3)}
+       "tests_per_ray": round(s["tri_tests"] / s["rays"], 3), "stack_high_water_mean": round(s["stack_sum"] / max(1, s["rays"] - s.get("rays_untraced", 0)), 3),
+       "stack_max": s["stack_max"]}
 r.set_spp(a.spp)
 ms = []
 for i in range(3):
