@@ -225,6 +225,8 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
             t[x].area = b.half_area();
         }
     };
+    double margin = 0.0;
+    if (const char* e_ = std::getenv("CRT_SAH_OPT_MARGIN")) margin = std::atof(e_);
     struct Cand { double ind; int x; };
     auto cmp = [](const Cand& a, const Cand& b) { return a.ind > b.ind; };
     std::vector<Cand> heap;
@@ -263,6 +265,19 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
                     if (ind + ax < best)
                         for (int s2 = 0; s2 < 2; s2++) { heap.push_back(Cand{ind, t[c.x].child[s2]}); std::push_heap(heap.begin(), heap.end(), cmp); }
                 }
+            }
+            // a move must pay: what putting x back beside its old sibling would cost, and the margin a new place has to beat it by
+            // (CRT_SAH_OPT_MARGIN, default 0: any improvement) -- reinsertions that gain next to nothing only stir up overlap
+            if (margin > 0.0 && best_x != S) {
+                Box u = t[S].box;
+                u.grow(bx);
+                double orig = u.half_area();
+                for (int y = t[S].parent; y >= 0; y = t[y].parent) {
+                    Box v = t[y].box;
+                    v.grow(bx);
+                    orig += v.half_area() - t[y].area;
+                }
+                if (!(best < orig * (1.0 - margin))) best_x = S;
             }
             // P becomes the parent of (best_x, x) in best_x's place
             const int Q = t[best_x].parent;
