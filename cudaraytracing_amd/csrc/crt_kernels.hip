@@ -40,6 +40,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace crtdev;
@@ -948,7 +949,16 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #ifndef CRT_WAVES
 #define CRT_WAVES 4   /* waves per SIMD the kernel is compiled for; the LDS footprint of a pool must allow it (160 KiB per CU) */
 #endif
-struct Pool3Lds {
+// R16: the traversal stack holds 16-bit node refs, twice as many levels in the same bytes (scenes whose 4-wide tree and leaf records
+// number at most 32 768 each: crt_scene::ref16_ok).  The levels beyond LDS cost a wave-uniform branch with 64-bit address arithmetic,
+// global stores and -- in the pop -- an exposed global load whenever ANY ray of a batch is that deep, which with three levels is
+// most batches (stamps: 830 of 5 800 cycles of an inner step, 560 of 4 100 of a leaf step); with six it is rare.  A ray on the
+// reference-arithmetic path (RF_EXACT: refs of the 2-wide trees, which do not fit) keeps its whole stack in the global area then.
+template <bool R16_>
+struct Pool3LdsT {
+    static constexpr bool R16 = R16_;
+    static constexpr int LV = R16_ ? 2 * POOL_LV : POOL_LV;
+    typedef typename std::conditional<R16_, short, int>::type stk_t;
     float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
     float4 B[POOL3_P];           // direction.xyz, bits(best triangle, -1 = none)
 #if CRT_INV_LDS
@@ -956,10 +966,12 @@ struct Pool3Lds {
 #else
     int node[POOL3_P];           // current node ref
 #endif
-    int stk[POOL_LV][POOL3_P];   // traversal stack (node refs); deeper levels spill to global memory
+    stk_t stk[LV][POOL3_P];      // traversal stack (node refs); deeper levels spill to global memory
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N][POOL3_QCAP];
 };
+typedef Pool3LdsT<false> Pool3Lds;
+static_assert(sizeof(Pool3LdsT<true>) == sizeof(Pool3Lds), "16-bit stack entries: twice the levels in the same bytes");
 static_assert(sizeof(Pool3Lds) * 4 * CRT_WAVES <= 160 * 1024, "the pool does not fit CRT_WAVES waves per SIMD into 160 KiB of LDS");
 
 struct MParams3 {
@@ -1048,8 +1060,8 @@ __device__ __forceinline__ F3 inv3_exact(const F3 d)
 }
 
 // Writes the new ray into the pool record `id` and returns its first phase.
-template <int MODE, bool QUERY = false>
-__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, Pool3Lds& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
+template <int MODE, bool QUERY = false, class LDS = Pool3Lds>
+__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
 {
     cnt.rays++;
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
@@ -1473,15 +1485,18 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
 // distance to drop such entries here measured no gain on either scene and costs 4 B of LDS per level).  The LDS levels are
 // read unconditionally and the (rare) spilled levels behind a wave-uniform branch: a per-lane choice between the two address
 // spaces would compile to a flat load that waits on both memory pipes.
+// LDS levels of a ray: all of them, except for a ray on the reference-arithmetic path in the 16-bit layout (none)
 template <class LDS>
-__device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref)
+__device__ __forceinline__ int lds_levels(const bool exact) { return (LDS::R16 && exact) ? 0 : LDS::LV; }
+template <class LDS>
+__device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref, const int lv)
 {
     if (sp == 0) return true;
     sp--;
-    int en = S.stk[sp < POOL_LV ? sp : 0][id];
+    int en = S.stk[sp < lv ? sp : 0][id];
     asm volatile("" : "+v"(en)); // (pins the LDS read: see above)
-    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
-        if (sp >= POOL_LV) en = M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g];
+    if (__builtin_amdgcn_ballot_w64(sp >= lv)) {
+        if (sp >= lv) en = M3.spill[(size_t)(sp - lv) * M3.M.spill_stride + g];
     }
     ref = en;
     return false;
@@ -1492,34 +1507,34 @@ __device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint
 #define CRT_POP_AHEAD 1
 #endif
 template <class LDS>
-__device__ __forceinline__ int stack_top_ahead(LDS& S, const uint32_t id, const int sp)
+__device__ __forceinline__ int stack_top_ahead(LDS& S, const uint32_t id, const int sp, const int lv)
 {
-    const int lv = sp - 1;
-    return S.stk[(lv >= 0 && lv < POOL_LV) ? lv : 0][id];
+    const int top = sp - 1;
+    return S.stk[(top >= 0 && top < lv) ? top : 0][id];
 }
 template <class LDS>
-__device__ __forceinline__ bool stack_pop_ahead(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref, const int top)
+__device__ __forceinline__ bool stack_pop_ahead(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref, const int top, const int lv)
 {
 #if CRT_POP_AHEAD
     if (sp == 0) return true;
     sp--;
     int en = top;
-    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
-        if (sp >= POOL_LV) en = M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g];
+    if (__builtin_amdgcn_ballot_w64(sp >= lv)) {
+        if (sp >= lv) en = M3.spill[(size_t)(sp - lv) * M3.M.spill_stride + g];
     }
     ref = en;
     return false;
 #else
     (void)top;
-    return stack_pop(S, M3, id, g, sp, ref);
+    return stack_pop(S, M3, id, g, sp, ref, lv);
 #endif
 }
 template <class LDS>
-__device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref)
+__device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref, const int lv)
 {
-    if (sp < POOL_LV) S.stk[sp][id] = ref;
-    if (__builtin_amdgcn_ballot_w64(sp >= POOL_LV)) {
-        if (sp >= POOL_LV) M3.spill[(size_t)(sp - POOL_LV) * M3.M.spill_stride + g] = ref;
+    if (sp < lv) S.stk[sp][id] = (typename LDS::stk_t)ref;
+    if (__builtin_amdgcn_ballot_w64(sp >= lv)) {
+        if (sp >= lv) M3.spill[(size_t)(sp - lv) * M3.M.spill_stride + g] = ref;
     }
     sp++;
 }
@@ -1555,7 +1570,7 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
 #endif
 #if CRT_POP_AHEAD
-    const int top = stack_top_ahead(S, id, sp);
+    const int top = stack_top_ahead(S, id, sp, LDS::LV);
 #else
     const int top = 0;
 #endif
@@ -1590,21 +1605,23 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     // stack, farthest first
     const bool c0 = t0 < inf, c1 = t1 < inf, c2 = t2 < inf, c3 = t3 < inf;
     const int l3 = sp, l2 = l3 + (c3 ? 1 : 0), l1 = l2 + (c2 ? 1 : 0);
-    if (c3 & (l3 < POOL_LV)) S.stk[l3][id] = r3;
-    if (c2 & (l2 < POOL_LV)) S.stk[l2][id] = r2;
-    if (c1 & (l1 < POOL_LV)) S.stk[l1][id] = r1;
+    constexpr int LV = LDS::LV; // (a ray of this step is not on the reference-arithmetic path: all LDS levels are its own)
+    typedef typename LDS::stk_t stk_t;
+    if (c3 & (l3 < LV)) S.stk[l3][id] = (stk_t)r3;
+    if (c2 & (l2 < LV)) S.stk[l2][id] = (stk_t)r2;
+    if (c1 & (l1 < LV)) S.stk[l1][id] = (stk_t)r1;
     const int sp_new = l1 + (c1 ? 1 : 0);
-    if (__builtin_amdgcn_ballot_w64((sp_new > l3) & (sp_new > POOL_LV))) { // one check per step for the levels beyond LDS (sp_new - 1 is the highest written)
-        if (c3 & (l3 >= POOL_LV)) M.spill[(size_t)(l3 - POOL_LV) * M.M.spill_stride + g] = r3;
-        if (c2 & (l2 >= POOL_LV)) M.spill[(size_t)(l2 - POOL_LV) * M.M.spill_stride + g] = r2;
-        if (c1 & (l1 >= POOL_LV)) M.spill[(size_t)(l1 - POOL_LV) * M.M.spill_stride + g] = r1;
+    if (__builtin_amdgcn_ballot_w64((sp_new > l3) & (sp_new > LV))) { // one check per step for the levels beyond LDS (sp_new - 1 is the highest written)
+        if (c3 & (l3 >= LV)) M.spill[(size_t)(l3 - LV) * M.M.spill_stride + g] = r3;
+        if (c2 & (l2 >= LV)) M.spill[(size_t)(l2 - LV) * M.M.spill_stride + g] = r2;
+        if (c1 & (l1 >= LV)) M.spill[(size_t)(l1 - LV) * M.M.spill_stride + g] = r1;
     }
     sp = sp_new;
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
     CRT_SEC4(3, sp + r0)
 #undef CRT_SEC4
     if (c0) { ref = r0; return false; }
-    return stack_pop_ahead(S, M, id, g, sp, ref, top); // (no child was hit: nothing was pushed, the top is the one read above)
+    return stack_pop_ahead(S, M, id, g, sp, ref, top, LV); // (no child was hit: nothing was pushed, the top is the one read above)
 }
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
@@ -1632,20 +1649,23 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
     }
     const bool both = hl && hr, any = hl || hr;
     const int near_ref = both ? (left_first ? lref : rref) : (hl ? lref : rref);
+    const int lv = lds_levels<LDS>(true); // (the rays of this step are on the reference-arithmetic path)
     if (both) {
-        stack_push(S, M, id, g, sp, left_first ? rref : lref);
+        stack_push(S, M, id, g, sp, left_first ? rref : lref, lv);
         if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
     }
     if (any) { ref = near_ref; return false; }
-    return stack_pop(S, M, id, g, sp, ref);
+    return stack_pop(S, M, id, g, sp, ref, lv);
 }
 
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
-template <int MODE, bool STATS, bool ALL = false, bool QUERY = false>
+template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, CRT_WAVES))) void k_mega3(const MParams3 M3)
 {
-    __shared__ Pool3Lds S;
+    static_assert(!(R16 && MODE == 1), "CRT_TRAVERSAL_REFERENCE walks the 2-wide trees: 32-bit stack entries");
+    typedef Pool3LdsT<R16> LDS3;
+    __shared__ LDS3 S;
     const MParams& M = M3.M;
     const LParams& P = M.P;
     const DevScene& sc = P.sc; // (one copy of the scene pointers in scalar registers: the logic phases use P.sc too)
@@ -1868,8 +1888,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float T = qa.w;
                 int tri = __float_as_int(qb.w);
                 int sp = (int)(qd & 0xffu);
+                const int lv = lds_levels<LDS3>((qd & RF_EXACT) != 0);
 #if CRT_POP_AHEAD
-                const int top = stack_top_ahead(S, id, sp);
+                const int top = stack_top_ahead(S, id, sp, lv);
 #else
                 const int top = 0;
 #endif
@@ -1906,7 +1927,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 }
                 if (STATS) tc.leaf++;
                 if (!any_hit && tri >= 0) qd |= RF_HASHIT;
-                if (!done) done = stack_pop_ahead(S, M3, id, g, sp, ref, top);
+                if (!done) done = stack_pop_ahead(S, M3, id, g, sp, ref, top, lv);
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
@@ -2202,6 +2223,7 @@ struct crt_scene {
     int device = 0;
     DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4;
     int depth4 = 1; // depth of the 4-wide tree
+    bool ref16_ok = false; // refs of the 4-wide tree and of the leaf records fit 16 bits (k_mega3's 16-bit stack layout)
     uint32_t max_leaf = 0; // triangles in the largest leaf
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint4> lights;
@@ -2239,6 +2261,14 @@ struct crt_scene {
         if (h_counters) (void)hipHostFree(h_counters);
     }
 };
+
+// 16-bit stack entries: the scene allows it (crt_scene::ref16_ok) and CRT_REF16=0 does not forbid it
+static bool use_ref16(const crt_scene* sc, int mode)
+{
+    if (mode == 1 || !sc->ref16_ok) return false;
+    const char* e = std::getenv("CRT_REF16"); // CRT_REF16=0: the 32-bit layout whatever the scene (tests, A/B)
+    return !(e && e[0] == '0');
+}
 
 namespace {
 
@@ -2425,6 +2455,27 @@ uint32_t env_u32(const char* name, uint32_t dflt)
     return x > 0 ? (uint32_t)x : dflt;
 }
 
+// The instantiation of k_mega3 for a traversal mode (0 FAST, 1 REFERENCE, 2 EXACT), with or without counters, every sample traced
+// or not (FAST only), render or query form, 32- or 16-bit stack entries (never for REFERENCE)
+typedef void (*Mega3Kernel)(const MParams3);
+Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16)
+{
+    if (mode == 1) return query ? (Mega3Kernel)k_mega3<1, false, false, true> : stats ? (Mega3Kernel)k_mega3<1, true> : (Mega3Kernel)k_mega3<1, false>;
+    if (query) {
+        if (mode == 2) return r16 ? (Mega3Kernel)k_mega3<2, false, false, true, true> : (Mega3Kernel)k_mega3<2, false, false, true, false>;
+        return r16 ? (Mega3Kernel)k_mega3<0, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, true, false>;
+    }
+    if (mode == 2) {
+        if (stats) return r16 ? (Mega3Kernel)k_mega3<2, true, false, false, true> : (Mega3Kernel)k_mega3<2, true, false, false, false>;
+        return r16 ? (Mega3Kernel)k_mega3<2, false, false, false, true> : (Mega3Kernel)k_mega3<2, false, false, false, false>;
+    }
+    if (all) {
+        if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, true, false, true> : (Mega3Kernel)k_mega3<0, true, true, false, false>;
+        return r16 ? (Mega3Kernel)k_mega3<0, false, true, false, true> : (Mega3Kernel)k_mega3<0, false, true, false, false>;
+    }
+    if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, false, false, true> : (Mega3Kernel)k_mega3<0, true, false, false, false>;
+    return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true> : (Mega3Kernel)k_mega3<0, false, false, false, false>;
+}
 // Which pipeline renders: 4 = k_mega3 (the product), 2 = the wavefront pipeline (k_logic + k_trace).  k_mega3 keeps the best
 // triangle's offset inside its leaf in 16 bits, addresses nodes and leaf records with 32-bit byte offsets and the traversal stack
 // depth in 8 bits; scenes beyond any of these fall back to the wavefront pipeline, which has no such limits.  The CRT_TEST_*
@@ -2547,6 +2598,9 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             const bool exact = prm->traversal == CRT_TRAVERSAL_EXACT;
             const int lds_cap = POOL_LV;
             const int mode_id = (reference ? 2 : exact ? 4 : 0) + (want_stats ? 1 : 0);
+            const int mode3 = reference ? 1 : exact ? 2 : 0;
+            const bool r16 = use_ref16(sc, mode3);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 == 0 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16);
             const uint32_t pool_p = (uint32_t)POOL3_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
@@ -2555,12 +2609,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             {
                 // one wave per workgroup, pool_p rays per wave
                 auto q3 = [&](int* n) {
-                    hipError_t e = mode_id == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, false>, 64, 0)
-                                 : mode_id == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<0, true>, 64, 0)
-                                 : mode_id == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, false>, 64, 0)
-                                 : mode_id == 3 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<1, true>, 64, 0)
-                                 : mode_id == 4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<2, false>, 64, 0)
-                                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(n, k_mega3<2, true>, 64, 0);
+                    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern3, 64, 0);
                     if (e != hipSuccess || *n < 1) *n = 1;
                 };
                 q3(&per_cu);
@@ -2571,7 +2620,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             sc->p_vx.ensure(lanes); sc->p_la.ensure(lanes); sc->p_cc.ensure(lanes); sc->p_vn.ensure(lanes); sc->p_id.ensure(lanes);
             sc->p_rec_a.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
             sc->p_rec_b.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
-            const int spill_levels = std::max(1, sc->stack_cap - POOL_LV);
+            // (16-bit layout: a ray on the reference-arithmetic path keeps its whole stack in the global area)
+            const int spill_levels = r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - POOL_LV);
             sc->spill[0].ensure((size_t)spill_levels * lanes);
             Pool pool;
             std::memset(&pool, 0, sizeof(pool));
@@ -2619,14 +2669,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
-                    if (mode_id == 0 && (prm->flags & CRT_FLAG_TRACE_ALL)) hipLaunchKernelGGL((k_mega3<0, false, true>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 1 && (prm->flags & CRT_FLAG_TRACE_ALL)) hipLaunchKernelGGL((k_mega3<0, true, true>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 0) hipLaunchKernelGGL((k_mega3<0, false>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 1) hipLaunchKernelGGL((k_mega3<0, true>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 2) hipLaunchKernelGGL((k_mega3<1, false>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 3) hipLaunchKernelGGL((k_mega3<1, true>), dim3(blocks), dim3(64), 0, st, M3);
-                    else if (mode_id == 4) hipLaunchKernelGGL((k_mega3<2, false>), dim3(blocks), dim3(64), 0, st, M3);
-                    else hipLaunchKernelGGL((k_mega3<2, true>), dim3(blocks), dim3(64), 0, st, M3);
+                    hipLaunchKernelGGL(kern3, dim3(blocks), dim3(64), 0, st, M3);
                 }
                 HIP_CHECK(hipGetLastError());
                 if (s0 + ns >= s_end) HIP_CHECK(hipEventRecord(sc->ev_k1, st));
@@ -3102,6 +3145,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->dev.coord_max = coord_max;
         sc->depth4 = depth4;
         sc->accel.n_nodes4 = (uint32_t)(nodes4.size() / 8); sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
+        sc->ref16_ok = nodes4.size() / 8 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
@@ -3324,14 +3368,15 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             const bool reference = traversal == CRT_TRAVERSAL_REFERENCE;
             int per_cu = 1;
             const bool exact = traversal == CRT_TRAVERSAL_EXACT;
-            if ((reference ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<1, false, false, true>, 64, 0)
-                 : exact   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<2, false, false, true>, 64, 0)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mega3<0, false, false, true>, 64, 0)) != hipSuccess || per_cu < 1) per_cu = 1;
+            const int mode3 = reference ? 1 : exact ? 2 : 0;
+            const bool r16 = use_ref16(sc, mode3);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, false, false, true, r16);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern3, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
             const uint32_t pool_p = (uint32_t)POOL3_P;
             const uint32_t blocks = std::min<uint32_t>((n + pool_p - 1) / pool_p, (uint32_t)(sc->n_cus * per_cu));
             const uint32_t lanes = blocks * pool_p;
             sc->p_la.ensure(lanes); sc->p_id.ensure(lanes); sc->L.ensure(n);
-            sc->spill[0].ensure((size_t)std::max(1, sc->stack_cap - POOL_LV) * lanes);
+            sc->spill[0].ensure((size_t)(r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - POOL_LV)) * lanes);
             MParams3 M3;
             std::memset(&M3, 0, sizeof(M3));
             LParams& P = M3.M.P;
@@ -3346,9 +3391,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             M3.spill = (int*)sc->spill[0].p;
             M3.force_exact = force_exact ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), nullptr));
-            if (reference) hipLaunchKernelGGL((k_mega3<1, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
-            else if (exact) hipLaunchKernelGGL((k_mega3<2, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
-            else hipLaunchKernelGGL((k_mega3<0, false, false, true>), dim3(blocks), dim3(64), 0, nullptr, M3);
+            hipLaunchKernelGGL(kern3, dim3(blocks), dim3(64), 0, nullptr, M3);
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipDeviceSynchronize());
             std::vector<float4> res(n);
