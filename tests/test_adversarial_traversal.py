@@ -450,3 +450,32 @@ def test_raw_directions_with_infinite_components():
             assert np.array_equal(tri_r, tri_f) and np.array_equal(util.bits(t_r), util.bits(t_f)), mode
     finally:
         r.free()
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_both_stack_layouts(name, monkeypatch):
+    """k_mega3 keeps six 16-bit traversal-stack levels in LDS where the scene's refs fit (both benchmark scenes) and three 32-bit
+    levels otherwise (CRT_REF16=0 forces that layout); in the 16-bit layout a ray on the reference-arithmetic path keeps its whole
+    stack in the global spill area (CRT_FLAG_FORCE_EXACT puts every ray there).  Same frames, same ray counts, same closest hits."""
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    osc = util.oracle_scene(name)
+    r = crt.Render(util.host_scene(name), 3, t.P_RR, t.light_sample_n)
+    try:
+        orgb, omean, _, st = osc.render(eye, iv, fov, 96, 72, 3, t.P_RR, t.light_sample_n)
+        o, d = util.random_rays(name, 4096, seed=17)
+        otri, ot, _ = osc.intersect(o, d)
+        for ref16 in ("1", "0"):
+            monkeypatch.setenv("CRT_REF16", ref16)
+            for mode, flags in ((crt.TRAVERSAL_FAST, 0), (crt.TRAVERSAL_EXACT, 0), (crt.TRAVERSAL_FAST, crt.FLAG_FORCE_EXACT),
+                                (crt.TRAVERSAL_EXACT, crt.FLAG_FORCE_EXACT), (crt.TRAVERSAL_REFERENCE, 0)):
+                r.traversal, r.extra_flags = mode, flags
+                rgb = r.run_view(eye, iv, fov, width=96, height=72)
+                assert np.array_equal(rgb, orgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (ref16, mode, flags)
+                assert r.stats["rays"] == st["rays"]
+            r.extra_flags = 0
+            for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT, crt.TRAVERSAL_REFERENCE):
+                tri, tt = r.intersect(o, d, traversal=mode)
+                assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot)), (ref16, mode)
+    finally:
+        r.free()
