@@ -885,7 +885,7 @@ struct MParams {
 };
 
 #ifndef POOL_LV
-#define POOL_LV 3 /* traversal stack levels kept in LDS per ray; deeper levels spill to global memory */
+#define POOL_LV 4 /* 32-bit traversal stack levels kept in LDS per ray (twice as many of 16 bits, Pool3LdsT); deeper levels spill to global memory */
 #endif
 
 // --------------------------------------- megakernel, queued sub-phases ----
@@ -933,7 +933,9 @@ struct MParams {
 #define RF_SKIP 0x40000000u    /* (NewRay only) next-event sample with a zero contribution: answered without traversal */
 #define RF_QUERY 0x80000000u   /* crt_intersect: a bare closest-hit query; its result goes straight back to LC */
 #ifndef POOL3_P
-#define POOL3_P 148         /* 148 x 64 B + rings = 10 212 B: 16 waves per CU */
+#define POOL3_P 164         /* 164 x 56 B + rings = 10 004 B: 16 waves per CU (measured with the 16-bit stack layout: 148 rays x 64 B records
+                               with 1/d and six levels 102.5 ms, 176 x 52 B with six levels 100.2, 164 x 56 B with eight levels 98.8, 156 x 60 B with
+                               ten 100.0) */
 #endif
 #define POOL3_QCAP ((POOL3_P + 3) & ~3) /* ring capacity (any number >= POOL3_P: indices wrap by compare, not by mask); ids fit a byte */
 static_assert(POOL3_P <= 256, "ray ids of a pool must fit a byte (ring entries are uint8_t)");
@@ -944,7 +946,8 @@ static_assert(POOL3_QCAP >= POOL3_P, "a ring must hold every ray of the pool");
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifndef CRT_INV_LDS
-#define CRT_INV_LDS 1 /* 1: 1/direction is part of the ray record (64 B per ray); 0: the inner step recomputes it from the direction (52 B per ray) */
+#define CRT_INV_LDS 0 /* 1: 1/direction is part of the ray record (+12 B per ray); 0: the inner step recomputes it from the direction (short exact
+                         reciprocals, +13 instructions per step) -- since the stack entries are 16 bits wide the larger pool pays for them */
 #endif
 #ifndef CRT_WAVES
 #define CRT_WAVES 4   /* waves per SIMD the kernel is compiled for; the LDS footprint of a pool must allow it (160 KiB per CU) */
