@@ -116,7 +116,7 @@ enum {
     CRT_TRAVERSAL_EXACT = 2      /* CRT_TRAVERSAL_FAST without its pruning rule: the 4-wide tree over the reference's leaves, nearest child
                                     first, any-hit visibility rays, zero-contribution samples answered without traversal -- every step of
                                     it provably result-neutral, so the frame is REFERENCE's bit for bit; measured
-                                    C2 +7 %, veach-mis +29 % against FAST (REFERENCE: 4 x / 6 x) */
+                                    C2 +6 %, veach-mis +26 % against FAST (REFERENCE: 4 x / 6 x) */
 };
 enum {
     CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (slower counting kernels) */
