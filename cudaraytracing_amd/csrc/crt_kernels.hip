@@ -1319,6 +1319,20 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
+    // The next work item is asked for NOW -- one atomic on the wave's home cursor for all its lanes -- and looked at after the
+    // backward recursion: the cursor's round trip hides behind the recursion's own loads (the earlier attempt read the answer with
+    // a readfirstlane at once, which waits).  A home shard that has run dry (the end of a launch) falls back to grab_item below.
+#ifndef CRT_GRAB_AHEAD
+#define CRT_GRAB_AHEAD 1
+#endif
+    const uint32_t home_ = blockIdx.x & (ITEM_SHARDS - 1);
+    const uint32_t lo_ = home_ * P.items_per_shard, hi_ = min(lo_ + P.items_per_shard, P.n_items);
+    const unsigned long long gmask_ = __ballot(1);
+    const int lane_ = threadIdx.x & 63;
+    const uint32_t grank_ = (uint32_t)__popcll(gmask_ & ((1ull << lane_) - 1ull));
+    unsigned int pre_base_ = 0;
+    const bool pre_ok_ = CRT_GRAB_AHEAD && lo_ < P.n_items;
+    if (pre_ok_ && lane_ == __ffsll((long long)gmask_) - 1) pre_base_ = atomicAdd(P.item_next + home_ * ITEM_STRIDE, (unsigned int)__popcll(gmask_));
     if (stage != ST_NEW) {
         int deepest = (int)depth;
         bool emissive = false;
@@ -1336,8 +1350,15 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         __builtin_nontemporal_store(L.y, &P.L[idv.z].y);
         __builtin_nontemporal_store(L.z, &P.L[idv.z].z);
     }
+    bool first_ = pre_ok_;
     for (;;) {
-        const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
+        uint32_t item = ITEM_NONE;
+        if (first_) { // the answer of the atomic issued above (the leader is the first active lane)
+            const unsigned long long idx_ = (unsigned long long)lo_ + (unsigned int)__builtin_amdgcn_readfirstlane((int)pre_base_) + grank_;
+            if (idx_ < hi_) item = (uint32_t)idx_;
+            first_ = false;
+        }
+        if (item == ITEM_NONE) item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
         if (item == ITEM_NONE) return false;
         bool valid; uint32_t pi, pj, pixel_index, k;
         decode_item(P, item, pixel_index, k, valid, pi, pj);
