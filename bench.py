@@ -71,7 +71,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--spp", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--traversal", default="fast", choices=["fast", "exact", "reference"])
+    ap.add_argument("--traversal", default="exact", choices=["exact", "fast", "reference"],
+                    help="exact (default): provably the reference's frame; fast: + distance pruning (measured rate of lost rays, include/crt.h)")
     ap.add_argument("--engine", default="procs", choices=["procs", "multi"],
                     help="procs: one process per GPU, torch.distributed over RCCL; multi: one process, crt_multi_render")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -329,15 +330,22 @@ def main_rank(args):
         ref_mean, ref_rgb, ref_rays = render.mean_buffer.copy(), render.frame_buffer.copy(), render.stats["rays"]
         b_ray = visit_bytes(render.stats)
         ref_visits = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
-        render.traversal = crt.TRAVERSAL_FAST
-        render.run_view(eye, inv_view, fov, stats=True, want_mean=True, width=args.width, height=args.height)
-        b_ray_visited = visit_bytes(render.stats, 112.0)  # the FAST traversal walks the 4-wide tree: 4 boxes + 4 refs per node
-        fast_visits = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
-        fast_vs_reference = {
-            "sample": "%s %dx%d spp=8, all pixels" % (args.scene, args.width, args.height),
-            "pixels_differ_f32_bits": int(np.count_nonzero(np.any(render.mean_buffer.view(np.uint32) != ref_mean.view(np.uint32), axis=2))),
-            "rgb8_mismatch": int(np.count_nonzero(np.any(render.frame_buffer != ref_rgb, axis=2))),
-            "rays_equal": bool(render.stats["rays"] == ref_rays)}
+        # the two production modes on the same slice: their visit sets, and their frames against REFERENCE's (every pixel, float bits)
+        vs_reference, visits = {}, {}
+        b_ray_visited = None
+        for mname, mode in (("exact", crt.TRAVERSAL_EXACT), ("fast", crt.TRAVERSAL_FAST)):
+            render.traversal = mode
+            render.run_view(eye, inv_view, fov, stats=True, want_mean=True, width=args.width, height=args.height)
+            visits[mname] = {k: round(render.stats[k] / render.stats["rays"], 2) for k in ("inner_pops", "leaf_pops", "tri_tests", "hits")}
+            if mode == trav or b_ray_visited is None:
+                b_ray_visited = visit_bytes(render.stats, 112.0)  # the 4-wide tree: 4 boxes + 4 refs per node
+            vs_reference[mname] = {
+                "sample": "%s %dx%d spp=8, all pixels" % (args.scene, args.width, args.height),
+                "pixels_differ_f32_bits": int(np.count_nonzero(np.any(render.mean_buffer.view(np.uint32) != ref_mean.view(np.uint32), axis=2))),
+                "rgb8_mismatch": int(np.count_nonzero(np.any(render.frame_buffer != ref_rgb, axis=2))),
+                "rays_equal": bool(render.stats["rays"] == ref_rays)}
+        fast_vs_reference, exact_vs_reference = vs_reference["fast"], vs_reference["exact"]
+        render.traversal = trav
         launches = max(1, int(np.mean(kernel_launches)))
         k_ms_total = float(np.mean(kernel_ms))           # sum of the kernel's launch durations of one frame (rank 0 / slowest rank)
         k_ms = k_ms_total / launches                     # average launch duration
@@ -351,8 +359,8 @@ def main_rank(args):
                     "contract_bytes_per_ray": round(b_ray, 1), "contract_achieved": round(contract, 2),
                     "contract_frac": round(contract / HBM_PEAK_GBPS, 4), "contract_unit": "GB/s",
                     "contract_note": "SURVEY 8(d): algorithmic bytes of the REFERENCE traversal's visit set / kernel time; the kernel "
-                                     "does not perform that work (4-wide SAH tree over the same leaves, pruning, any-hit), so this is not a bound",
-                    "reference_visits_per_ray": ref_visits, "fast_visits_per_ray": fast_visits,
+                                     "does not perform that work (4-wide SAH tree over the same leaves, any-hit visibility rays, untraced zero-contribution samples), so this is not a bound",
+                    "reference_visits_per_ray": ref_visits, "exact_visits_per_ray": visits["exact"], "fast_visits_per_ray": visits["fast"],
                     "visited_bytes_per_ray": round(b_ray_visited, 1), "visited_achieved": round(contract_visited, 2)}
         pmc, pmc_note = (load_pmc("c2") if (c2 and single) else (None, "PMC passes exist for the C2 workload on one GPU only"))
         if pmc is not None:
@@ -389,26 +397,29 @@ def main_rank(args):
             all_traced = {"ms_per_step": round(dt_all * 1e3, 3), "mrays_per_sec": round(st_all["rays"] / dt_all / 1e6, 2),
                           "kernel_ms": round(st_all["kernel_ms"], 3)}
 
-        # ---- the same frame in CRT_TRAVERSAL_EXACT (the fast traversal without its pruning rule: provably the reference's frame,
-        #      DESIGN.md 4.3), timed and compared with the frame of the timed steps ----
-        exact_mode = None
-        if single and not multi and trav == crt.TRAVERSAL_FAST:
+        # ---- the same frame in the OTHER of the two production modes, timed and compared with the frame of the timed steps:
+        #      CRT_TRAVERSAL_EXACT (default; provably the reference's frame) against CRT_TRAVERSAL_FAST (+ distance pruning) ----
+        other_mode = None
+        other_name = None
+        if single and not multi and trav in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):
+            other = crt.TRAVERSAL_EXACT if trav == crt.TRAVERSAL_FAST else crt.TRAVERSAL_FAST
+            other_name = "exact_mode" if other == crt.TRAVERSAL_EXACT else "fast_mode"
             render.set_spp(args.spp)
-            render.traversal = crt.TRAVERSAL_FAST
-            fast_img, _ = step()
-            fast_img = fast_img.clone() if hasattr(fast_img, "clone") else np.array(fast_img)
-            render.traversal = crt.TRAVERSAL_EXACT
+            render.traversal = trav
+            own_img, _ = step()
+            own_img = own_img.clone() if hasattr(own_img, "clone") else np.array(own_img)
+            render.traversal = other
             step()
             torch.cuda.synchronize(device)
             c0 = time.perf_counter()
-            ex_img, st_ex = step()
+            ot_img, st_ot = step()
             torch.cuda.synchronize(device)
-            dt_ex = time.perf_counter() - c0
+            dt_ot = time.perf_counter() - c0
             render.traversal = trav
-            same = bool((ex_img == fast_img).all()) if hasattr(ex_img, "all") else None
-            exact_mode = {"traversal": "exact", "ms_per_step": round(dt_ex * 1e3, 3), "kernel_ms": round(st_ex["kernel_ms"], 3),
-                          "mrays_per_sec": round(st_ex["rays"] / dt_ex / 1e6, 2), "rgb8_frame_equals_fast_frame": same,
-                          "rays_equal": bool(st_ex["rays"] == rays_local)}
+            same = bool((ot_img == own_img).all()) if hasattr(ot_img, "all") else None
+            other_mode = {"traversal": "exact" if other == crt.TRAVERSAL_EXACT else "fast", "ms_per_step": round(dt_ot * 1e3, 3),
+                          "kernel_ms": round(st_ot["kernel_ms"], 3), "mrays_per_sec": round(st_ot["rays"] / dt_ot / 1e6, 2),
+                          "rgb8_frame_equals_timed_frame": same, "rays_equal": bool(st_ot["rays"] == rays_local)}
 
         # ---- C3 (veach-mis 800x600 spp=1024: divergence stress) timed by the same run ----
         c3 = None
@@ -417,6 +428,7 @@ def main_rank(args):
             s3 = crt.Scene.from_task(t3, 800, 600)
             r3 = crt.Render(s3, 1024, t3.P_RR, t3.light_sample_n, device=local_rank)
             r3.seed = args.seed
+            r3.traversal = trav
             iv3 = crt.get_inverse_view_matrix(t3.eye_pos, t3.lookat, t3.up)
             f3 = crt.fov_to_radians(t3.fov_y)
 
@@ -440,20 +452,22 @@ def main_rank(args):
             torch.cuda.synchronize(device)
             dt3a = time.perf_counter() - c0
             r3.extra_flags = 0
-            r3.traversal = crt.TRAVERSAL_EXACT
+            other3 = crt.TRAVERSAL_FAST if trav == crt.TRAVERSAL_EXACT else crt.TRAVERSAL_EXACT
+            r3.traversal = other3
             step3()
             torch.cuda.synchronize(device)
             c0 = time.perf_counter()
             step3()
             torch.cuda.synchronize(device)
             dt3e = time.perf_counter() - c0
-            r3.traversal = crt.TRAVERSAL_FAST
+            r3.traversal = trav
             c3 = {"workload": "veach-mis 800x600 spp=1024 P_RR=%g light_sample_n=%d" % (float(t3.P_RR), t3.light_sample_n), "frames": 3,
                   "ms_per_frame": round(dt3 * 1e3, 3), "kernel_ms": round(float(np.mean(k3)), 3), "rays_per_frame": int(st3["rays"]),
                   "mrays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
                   "mrays_traced_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),
                   "untraced_frac": round(st3["rays_untraced"] / st3["rays"], 4),
-                  "all_rays_traced_ms": round(dt3a * 1e3, 3), "exact_mode_ms": round(dt3e * 1e3, 3)}
+                  "all_rays_traced_ms": round(dt3a * 1e3, 3),
+                  ("fast_mode_ms" if other3 == crt.TRAVERSAL_FAST else "exact_mode_ms"): round(dt3e * 1e3, 3)}
             p3, _ = load_pmc("c3")
             if p3 is not None:
                 c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3)
@@ -529,9 +543,10 @@ def main_rank(args):
             "rays_untraced_per_frame_rank0": int(untraced_local),
             "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
             "all_rays_traced": all_traced,
-            "exact_mode": exact_mode,
+            **({other_name: other_mode} if other_name else {}),
             "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
             "roofline": roofline,
+            "exact_vs_reference": exact_vs_reference,
             "fast_vs_reference": fast_vs_reference,
         }
         if multi:

@@ -8,9 +8,9 @@ import numpy as np
 from . import build as _build
 
 CRT_OK = 0
-TRAVERSAL_FAST = 0
+TRAVERSAL_EXACT = 0      # the default: provably the reference's frame
 TRAVERSAL_REFERENCE = 1
-TRAVERSAL_EXACT = 2
+TRAVERSAL_FAST = 2       # + distance pruning (measured rate of lost rays, include/crt.h)
 FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4

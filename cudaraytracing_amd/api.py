@@ -159,7 +159,7 @@ class Render:
         self.scene = scene
         self.spp, self.P_RR, self.light_sample_n = int(spp), np.float32(P_RR), int(light_sample_n)
         self.seed = 0
-        self.traversal = capi.TRAVERSAL_FAST
+        self.traversal = capi.TRAVERSAL_EXACT
         self.extra_flags = 0  # e.g. FLAG_FORCE_EXACT (test hook)
         self.device = device
         self._h = C.c_void_p()
@@ -316,7 +316,7 @@ class MultiRender(Render):
         self.scene = scene
         self.spp, self.P_RR, self.light_sample_n = int(spp), np.float32(P_RR), int(light_sample_n)
         self.seed = 0
-        self.traversal = capi.TRAVERSAL_FAST
+        self.traversal = capi.TRAVERSAL_EXACT
         self.extra_flags = 0
         self.devices = [int(d) for d in devices]
         self.device = self.devices[0]

@@ -233,7 +233,7 @@ private:
     unsigned spp_, light_sample_n_;
     float P_RR_;
     uint64_t seed_ = 0;
-    uint32_t traversal_ = CRT_TRAVERSAL_FAST;
+    uint32_t traversal_ = CRT_TRAVERSAL_EXACT;
     crt_scene* device_scene_ = nullptr;
     crt_multi* multi_ = nullptr;
     crt_multi_info multi_info_{};

@@ -2490,6 +2490,10 @@ Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16)
         return r16 ? (Mega3Kernel)k_mega3<0, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, true, false>;
     }
     if (mode == 2) {
+        if (all) {
+            if (stats) return r16 ? (Mega3Kernel)k_mega3<2, true, true, false, true> : (Mega3Kernel)k_mega3<2, true, true, false, false>;
+            return r16 ? (Mega3Kernel)k_mega3<2, false, true, false, true> : (Mega3Kernel)k_mega3<2, false, true, false, false>;
+        }
         if (stats) return r16 ? (Mega3Kernel)k_mega3<2, true, false, false, true> : (Mega3Kernel)k_mega3<2, true, false, false, false>;
         return r16 ? (Mega3Kernel)k_mega3<2, false, false, false, true> : (Mega3Kernel)k_mega3<2, false, false, false, false>;
     }
@@ -2624,7 +2628,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             const int mode_id = (reference ? 2 : exact ? 4 : 0) + (want_stats ? 1 : 0);
             const int mode3 = reference ? 1 : exact ? 2 : 0;
             const bool r16 = use_ref16(sc, mode3);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 == 0 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16);
             const uint32_t pool_p = (uint32_t)POOL3_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));

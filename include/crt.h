@@ -100,28 +100,27 @@ typedef struct {
 } crt_camera;
 
 enum {
-    CRT_TRAVERSAL_FAST = 0,      /* ordered, pruned, any-hit visibility rays.  Ordering, the 4-wide tree and any-hit are provably result-neutral;
-                                    the pruning rule (csrc/crt_trace.h: skip a box entered beyond t_ref + 0.1 % + 1e-3 + 1e-4 x reach x steep, reach
-                                    = max |origin coordinate| + t_ref, steep = max |1 / direction component|) is exact unless a
-                                    Moeller-Trumbore hit lies further in front of its own leaf box than that slack, which happens for rays
-                                    lying in the plane of a triangle (det -> 0: unbounded error, and the reference has no determinant
-                                    threshold).  MEASURED (tools/soak_fast_vs_reference.py, profiles/r02_soak_fast_vs_reference.jsonl): 2 rays in
-                                    3.66e11 on full 1920x1080x4096 veach-mis frames (tessellated spheres; each changes one next-event sample:
-                                    the last bit of one pixel), 0 in 3.4e11 on full 3840x2160x256 cornell-box frames; a larger factor only thins
-                                    them out.  Bit-identical to REFERENCE on every frame and probe of the test-suite
-                                    (tests/test_production_sizes.py, tests/test_adversarial_traversal.py -- two lost rays are kept there as
-                                    known answers), and bench.py re-checks a slice of the benchmark frame against REFERENCE in every run.
-                                    Use CRT_TRAVERSAL_EXACT (or REFERENCE) where bit-exactness must be unconditional. */
+    CRT_TRAVERSAL_EXACT = 0,     /* THE DEFAULT (a zeroed crt_params): the 4-wide tree over the reference's leaves, nearest child first, any-hit
+                                    visibility rays, zero-contribution samples answered without traversal -- every step of it provably
+                                    result-neutral, so the frame is REFERENCE's bit for bit (soak: 3.9e11 rays of
+                                    full-size frames, 0 pixel slots differ) at 1/4 .. 1/6 of REFERENCE's time */
     CRT_TRAVERSAL_REFERENCE = 1, /* exhaustive traversal in the reference's visit order (DeviceBVH.cuh:128-170) */
-    CRT_TRAVERSAL_EXACT = 2      /* CRT_TRAVERSAL_FAST without its pruning rule: the 4-wide tree over the reference's leaves, nearest child
-                                    first, any-hit visibility rays, zero-contribution samples answered without traversal -- every step of
-                                    it provably result-neutral, so the frame is REFERENCE's bit for bit; measured
-                                    C2 +6 %, veach-mis +26 % against FAST (REFERENCE: 4 x / 6 x) */
+    CRT_TRAVERSAL_FAST = 2       /* CRT_TRAVERSAL_EXACT plus distance pruning: skip a box entered beyond t_ref + 0.1 % + 1e-3 + 1e-4 x reach x steep
+                                    (csrc/crt_trace.h; reach = max |origin coordinate| + t_ref, steep = max |1 / direction component|).  C2 -7 %,
+                                    veach-mis -21 % frame time.  Exact unless a Moeller-Trumbore hit lies further in front of its own leaf box
+                                    than that slack, which happens for rays lying in the plane of a triangle (det -> 0: unbounded error, and
+                                    the reference has no determinant threshold).  MEASURED (tools/soak_fast_vs_reference.py,
+                                    profiles/r02_soak_fast_vs_reference.jsonl): 2 rays in 3.66e11 on full 1920x1080x4096 veach-mis frames
+                                    (tessellated spheres; each changes one next-event sample: the last bit of one pixel), 0 in 3.4e11 on full
+                                    3840x2160x256 cornell-box frames; a larger slack only thins them out.
+                                    Bit-identical to REFERENCE on every frame and probe of the test-suite (two lost rays are kept as known
+                                    answers in tests/test_adversarial_traversal.py); bench.py times it beside the default and re-checks a
+                                    slice of the benchmark frame against REFERENCE in every run */
 };
 enum {
     CRT_FLAG_STATS = 1u,         /* fill the traversal counters of crt_stats (slower counting kernels) */
     CRT_FLAG_TILED_OUTPUT = 2u,  /* write this rank's pixels in compact 8x8-tile order instead of row-major */
-    CRT_FLAG_TRACE_ALL = 8u,     /* CRT_TRAVERSAL_FAST traces every next-event sample, also those whose contribution is exactly
+    CRT_FLAG_TRACE_ALL = 8u,     /* CRT_TRAVERSAL_EXACT / _FAST trace every next-event sample, also those whose contribution is exactly
                                     zero (crt_stats.rays_untraced stays 0); same frame, for measuring the traversal alone */
     CRT_FLAG_FORCE_EXACT = 4u    /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
                                     box arithmetic on the reference topology, still pruned / any-hit); results are unchanged */

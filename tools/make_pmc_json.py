@@ -15,9 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cudaraytracing_amd import build as B
 
-# the default render path: FAST traversal, no counting, zero-contribution samples answered without traversal, not the query form
-DEFAULT_KERNEL = ("k_mega3<0, false, false, false, true>", "k_mega3<0, false, false, false, false>", "k_mega3<0, false, false, false>",
-                  "k_mega3<0, false, false>", "k_mega3<0, false>")  # the default render path: 16-bit stack layout if the scene allows it
+# the default render path: EXACT traversal (FAST as a fallback for older profiles), no counting, zero-contribution samples answered without traversal, not the query form
+DEFAULT_KERNEL = ("k_mega3<2, false, false, false, true>", "k_mega3<2, false, false, false, false>",
+                  "k_mega3<0, false, false, false, true>", "k_mega3<0, false, false, false, false>", "k_mega3<0, false, false, false>",
+                  "k_mega3<0, false, false>", "k_mega3<0, false>")  # the default render path: CRT_TRAVERSAL_EXACT, 16-bit stack layout if the scene allows it
 root = sys.argv[1]
 # Issue cost of one wave64 vector instruction on one SIMD of gfx950, by counter class, measured with tools/valu_issue_bench.hip
 # (independent streams, 4 and 8 waves per SIMD; profiles/r02_valu_issue.json): v_add_f32 / v_mul_f32 / v_mov_b32 / v_and_b32 2.5

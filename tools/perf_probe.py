@@ -11,7 +11,7 @@ ap.add_argument("--width", type=int, default=800)
 ap.add_argument("--height", type=int, default=600)
 ap.add_argument("--spp", type=int, default=512)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--traversal", default="fast")
+ap.add_argument("--traversal", default="exact", help="exact (the default mode), fast, reference")
 a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, a.width, a.height)

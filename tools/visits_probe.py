@@ -12,6 +12,7 @@ a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, 800, 600)
 r = crt.Render(sc, 8, t.P_RR, t.light_sample_n)
+r.traversal = {"exact": crt.TRAVERSAL_EXACT, "fast": crt.TRAVERSAL_FAST}[os.environ.get("CRT_PROBE_TRAVERSAL", "exact")]
 iv = crt.get_inverse_view_matrix(t.eye_pos, t.lookat, t.up); fov = crt.fov_to_radians(t.fov_y)
 r.run_view(t.eye_pos, iv, fov, stats=True, want_mean=False)
 s = r.stats
