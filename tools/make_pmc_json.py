@@ -38,7 +38,7 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
     if not os.path.exists(f):
         continue
     d = json.load(open(f))
-    ks = [n for n in d if n in DEFAULT_KERNEL]
+    ks = [n for n in DEFAULT_KERNEL if n in d]
     if not ks:
         continue
     v = dict(d[ks[0]])
@@ -67,8 +67,10 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
 f = os.path.join(root, "stats_summary.json")
 if os.path.exists(f):
     d = json.load(open(f))
-    for n, v in d.items():
-        if n in DEFAULT_KERNEL and "stats" in v and "c2" in res["workloads"]:
+    for n in DEFAULT_KERNEL:  # (in order of preference: the kernel of the default mode)
+        v = d.get(n)
+        if v and "stats" in v and "c2" in res["workloads"]:
             res["workloads"]["c2"]["avg_launch_ms"] = round(float(v["stats"]["AverageNs"]) / 1e6, 3)
             res["workloads"]["c2"]["stats_calls"] = int(v["stats"]["Calls"])
+            break
 print(json.dumps(res, indent=1))
