@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
 // near and far planes (picked by the sign of the direction, the reference's own swap), the nearest hit child next, the others pushed
 // farthest first.  Which children are visited, and in which order, does not change the result (crt_trace.h); the boxes and the test
 // are the reference's (hit_AABB, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
-template <bool STATS, class LDS>
+template <bool STATS, bool SORT = true, class LDS = Pool3Lds>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
                                             const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu
 #ifdef CRT_STAMPS
@@ -1623,7 +1623,11 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
 #define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
     // (leaving out the last exchange -- nearest first, farthest last, the middle two as they come -- saves 5 instructions per step
     // and costs more visits than that: C2 +1.5 %, veach-mis -0.3 %)
-    CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2) CRT_CE(t1, r1, t3, r3) CRT_CE(t1, r1, t2, r2)
+    if (SORT) {
+        CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2) CRT_CE(t1, r1, t3, r3) CRT_CE(t1, r1, t2, r2)
+    } else { // (CRT_TRAVERSAL_EXACT: only the nearest child to the front, CRT_SORT4)
+        CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2)
+    }
 #undef CRT_CE
     // the children to visit are a prefix of the sorted four (the pushes below do not rely on that); all but the nearest go on the
     // stack, farthest first
@@ -1682,6 +1686,14 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
     return stack_pop(S, M, id, g, sp, ref, lv);
 }
 
+// CRT_TRAVERSAL_EXACT visits every child that is hit whatever the order (no bound shrinks): it only brings the nearest to the front
+// (three exchanges instead of five: what the any-hit rays gain from a full order is less than the two exchanges cost -- C2 -0.7 %,
+// veach-mis -0.6 %); -DCRT_EXACT_FULLSORT restores the full network
+#ifdef CRT_EXACT_FULLSORT
+#define CRT_SORT4(mode) true
+#else
+#define CRT_SORT4(mode) ((mode) != 2)
+#endif
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
 template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false>
@@ -1868,9 +1880,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
 #ifdef CRT_STAMPS
-                    if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu, dg_sec, dg_t0);
+                    if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu, dg_sec, dg_t0);
 #else
-                    if (!ex) done = inner4_step<STATS>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
+                    if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
 #endif
                     if (__builtin_amdgcn_ballot_w64(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
                         if (ex) {
