@@ -1447,6 +1447,7 @@ __device__ __forceinline__ void slab_pair_pruned(const float4 n0, const float4 n
 #ifndef CRT_NODE_SIGNSEL
 #define CRT_NODE_SIGNSEL 1
 #endif
+template <bool PRUNE = true>
 __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
                                                  const F3 o, const F3 inv, const float bound, float& t0, float& t1, float& t2, float& t3)
 {
@@ -1459,10 +1460,17 @@ __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 f
     const float e0 = fmax3(nxa.x, nya.x, nza.x), e1 = fmax3(nxa.y, nya.y, nza.y), e2 = fmax3(nxb.x, nyb.x, nzb.x), e3 = fmax3(nxb.y, nyb.y, nzb.y);
     const float x0 = fmin3(fxa.x, fya.x, fza.x), x1 = fmin3(fxa.y, fya.y, fza.y), x2 = fmin3(fxb.x, fyb.x, fzb.x), x3 = fmin3(fxb.y, fyb.y, fzb.y);
     const float inf = pinf();
-    t0 = ((e0 <= __builtin_fminf(x0 + CRT_EPSILON, bound)) & (x0 >= 0)) ? e0 : inf;
-    t1 = ((e1 <= __builtin_fminf(x1 + CRT_EPSILON, bound)) & (x1 >= 0)) ? e1 : inf;
-    t2 = ((e2 <= __builtin_fminf(x2 + CRT_EPSILON, bound)) & (x2 >= 0)) ? e2 : inf;
-    t3 = ((e3 <= __builtin_fminf(x3 + CRT_EPSILON, bound)) & (x3 >= 0)) ? e3 : inf;
+    if (PRUNE) {
+        t0 = ((e0 <= __builtin_fminf(x0 + CRT_EPSILON, bound)) & (x0 >= 0)) ? e0 : inf;
+        t1 = ((e1 <= __builtin_fminf(x1 + CRT_EPSILON, bound)) & (x1 >= 0)) ? e1 : inf;
+        t2 = ((e2 <= __builtin_fminf(x2 + CRT_EPSILON, bound)) & (x2 >= 0)) ? e2 : inf;
+        t3 = ((e3 <= __builtin_fminf(x3 + CRT_EPSILON, bound)) & (x3 >= 0)) ? e3 : inf;
+    } else { // no bound (CRT_TRAVERSAL_EXACT): hit_AABB's own test
+        t0 = ((e0 <= x0 + CRT_EPSILON) & (x0 >= 0)) ? e0 : inf;
+        t1 = ((e1 <= x1 + CRT_EPSILON) & (x1 >= 0)) ? e1 : inf;
+        t2 = ((e2 <= x2 + CRT_EPSILON) & (x2 >= 0)) ? e2 : inf;
+        t3 = ((e3 <= x3 + CRT_EPSILON) & (x3 >= 0)) ? e3 : inf;
+    }
 }
 
 // The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
@@ -1602,7 +1610,7 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
 #if CRT_NODE_SIGNSEL
-    slab_quad_pruned(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3);
+    slab_quad_pruned<SORT>(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3); // (SORT == pruning mode: CRT_SORT4)
 #else
     slab_pair_pruned(a0, a1, a2, o, inv, bound, t0, t1);
     slab_pair_pruned(b0, b1, b2, o, inv, bound, t2, t3);
