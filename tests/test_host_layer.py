@@ -183,3 +183,30 @@ def test_bench_started_plainly_with_several_gpus_starts_its_ranks(tmp_path):
     assert r.returncode != 0
     assert r.stderr.count("needs a GPU") == 2, r.stderr[-2000:]
     assert "must be launched with" not in r.stderr
+
+
+def test_header_constants_match_the_python_mirror():
+    """include/crt.h is the contract: the enum values the Python mirror passes must be the header's, and the default traversal mode
+    (a zeroed crt_params) must be the provably exact one."""
+    import re
+    from cudaraytracing_amd import _capi as capi
+    hdr = open(os.path.join(util.ROOT, "include", "crt.h")).read()
+
+    def value(name):
+        m = re.search(r"\b%s\s*=\s*(0x[0-9a-fA-F]+|\d+)u?" % name, hdr) or re.search(r"#define\s+%s\s+(0x[0-9a-fA-F]+|\d+)u?" % name, hdr)
+        assert m, name
+        return int(m.group(1), 0)
+
+    assert value("CRT_TRAVERSAL_EXACT") == capi.TRAVERSAL_EXACT == 0
+    assert value("CRT_TRAVERSAL_REFERENCE") == capi.TRAVERSAL_REFERENCE
+    assert value("CRT_TRAVERSAL_FAST") == capi.TRAVERSAL_FAST
+    for h, p in (("CRT_FLAG_STATS", capi.FLAG_STATS), ("CRT_FLAG_TILED_OUTPUT", capi.FLAG_TILED_OUTPUT), ("CRT_FLAG_TRACE_ALL", capi.FLAG_TRACE_ALL),
+                 ("CRT_FLAG_FORCE_EXACT", capi.FLAG_FORCE_EXACT), ("CRT_INTERSECT_RAW_DIRECTIONS", capi.INTERSECT_RAW_DIRECTIONS),
+                 ("CRT_INTERSECT_FORCE_EXACT", capi.INTERSECT_FORCE_EXACT), ("CRT_INTERSECT_VISIBILITY", capi.INTERSECT_VISIBILITY)):
+        assert value(h) == p, h
+    import cudaraytracing_amd as crt
+    sc = crt.Scene(8, 8)
+    # (a Render needs a GPU; the mirror's default is checked on the class attribute path instead)
+    import inspect
+    src = inspect.getsource(crt.Render.__init__)
+    assert "TRAVERSAL_EXACT" in src and "TRAVERSAL_FAST" not in src
