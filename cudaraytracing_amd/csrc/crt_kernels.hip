@@ -104,6 +104,7 @@ struct LParams {
     unsigned long long* counters;
     const float4* q_o;      // crt_intersect: origins / normalised directions of the query rays (work item = ray index)
     const float4* q_d;
+    const uint32_t* item_list; // NULL, or the order in which the work items of a cursor shard are handed out (k_order_items): [n_items]
 };
 
 struct TParams {
@@ -1360,6 +1361,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         }
         if (item == ITEM_NONE) item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
         if (item == ITEM_NONE) return false;
+        if (P.item_list) item = P.item_list[item]; // (small launches: paths that stop at their first vertex last, k_order_items)
         bool valid; uint32_t pi, pj, pixel_index, k;
         decode_item(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
@@ -2112,6 +2114,61 @@ __device__ __forceinline__ FastDiv make_fastdiv_dev(uint32_t d)
     return f;
 }
 
+// Orders the work items of every cursor shard: first the paths whose roulette draw lets them continue past their first vertex, then
+// the ones it stops there (and the padding slots of ragged tiles).  The draws are addressed (crt_detmath.h), so this is known before
+// anything is traced; the order of the work items cannot change a result (every path writes its own L[item]).  Why: every launch ends
+// with each wave running its pool dry, and the time that takes is the longest path started last -- with one-vertex paths at the
+// end of every shard the fixed cost of a launch drops from 2.5 ms to about 1 ms (tools/share_probe.py: a rank's share of C2 at 1 / 2 / 4 /
+// 8 ranks 106.2 / 54.2 / 28.1 / 15.7 ms without, 105.7 / 53.3 / 27.1 / 14.4 ms with, this pass included).  One wave orders a span of
+// 1 024 items of one shard with two atomics (a cache line per counter).
+__global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* list, unsigned int* cnt)
+{
+    const uint32_t spans = (P.items_per_shard + 1023u) / 1024u;
+    const uint32_t sh = blockIdx.x / spans, sp = blockIdx.x - sh * spans;
+    const uint32_t lo = sh * P.items_per_shard;
+    if (lo >= P.n_items) return;
+    const uint32_t hi = min(lo + P.items_per_shard, P.n_items);
+    const uint32_t b = lo + sp * 1024u;
+    if (b >= hi) return;
+    const uint32_t lane = threadIdx.x;
+    uint32_t goes_on = 0, exists = 0; // bit j: item b + 64 j + lane
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t i = b + j * 64u + lane;
+        if (i < hi) {
+            bool valid; uint32_t pi, pj, pixel_index, k;
+            decode_item(P, i, pixel_index, k, valid, pi, pj);
+            exists |= 1u << j;
+            // the roulette of the first vertex, as logic_B draws it (Render.cuh:223-227)
+            if (valid && !(rng_uniform(rng_draw(P.seed, pixel_index, k, 0, RNG_BOUNCE, 0).x) > P.p_rr)) goes_on |= 1u << j;
+        }
+    }
+    uint32_t n_on = 0, n_all = 0;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; j++) {
+        n_on += (uint32_t)__popcll(__ballot((goes_on >> j) & 1u));
+        n_all += (uint32_t)__popcll(__ballot((exists >> j) & 1u));
+    }
+    unsigned int base_on = 0, base_off = 0;
+    if (lane == 0) { // (one 128 B line per counter: the atomics of a shard serialise on their line, those of different shards must not)
+        base_on = atomicAdd(cnt + (sh * 2u) * 32u, n_on);
+        base_off = atomicAdd(cnt + (sh * 2u + 1u) * 32u, n_all - n_on);
+    }
+    base_on = (unsigned int)__builtin_amdgcn_readfirstlane((int)base_on);
+    base_off = (unsigned int)__builtin_amdgcn_readfirstlane((int)base_off);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 16; j++) {
+        const bool on_j = (goes_on >> j) & 1u, ex_j = (exists >> j) & 1u;
+        const unsigned long long m_on = __ballot(on_j), m_off = __ballot(ex_j && !on_j);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t i = b + j * 64u + lane;
+        if (on_j) list[lo + base_on + (uint32_t)__popcll(m_on & below)] = i;
+        else if (ex_j) list[hi - 1u - (base_off + (uint32_t)__popcll(m_off & below))] = i;
+        base_on += (unsigned int)__popcll(m_on);
+        base_off += (unsigned int)__popcll(m_off);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
 {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
@@ -2279,6 +2336,8 @@ struct crt_scene {
     DevBuf<float> accum;
     DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
     DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
+    DevBuf<uint32_t> item_list;               // k_order_items: the order of the work items of a launch (small launches only)
+    DevBuf<unsigned int> order_cnt;           // [ITEM_SHARDS][2] counters, one 128 B line each
     DevBuf<unsigned int> slot_next[2];        // [SLOT_SHARDS][SLOT_STRIDE], one per pool half
     DevBuf<int2> spill[2];                    // traversal stack overflow, one per pool half
     hipStream_t aux_stream = nullptr;         // second pool half runs here so that k_logic overlaps k_trace
@@ -2705,6 +2764,22 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 P.sample_begin = s0;
                 P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
+                // the paths that stop at their first vertex are handed out last (k_order_items): 1 % of a whole C2 frame on one GPU,
+                // 8 % of a rank's share on eight.  CRT_ITEM_ORDER=0 switches it off.
+                P.item_list = nullptr;
+                {
+                    const char* eo = std::getenv("CRT_ITEM_ORDER");
+                    const bool order = !(eo && eo[0] == '0');
+                    if (order && P.n_items > 0) {
+                        sc->item_list.ensure(P.n_items);
+                        sc->order_cnt.ensure((size_t)ITEM_SHARDS * 2 * 32);
+                        HIP_CHECK(hipMemsetAsync(sc->order_cnt.p, 0, (size_t)ITEM_SHARDS * 2 * 32 * sizeof(unsigned int), st));
+                        const uint32_t spans = (P.items_per_shard + 1023u) / 1024u;
+                        hipLaunchKernelGGL(k_order_items, dim3(ITEM_SHARDS * spans), dim3(64), 0, st, P, sc->item_list.p, sc->order_cnt.p);
+                        HIP_CHECK(hipGetLastError());
+                        P.item_list = sc->item_list.p;
+                    }
+                }
                 M.P = P;
                 HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
