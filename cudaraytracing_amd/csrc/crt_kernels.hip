@@ -104,7 +104,10 @@ struct LParams {
     unsigned long long* counters;
     const float4* q_o;      // crt_intersect: origins / normalised directions of the query rays (work item = ray index)
     const float4* q_d;
-    const uint32_t* item_list; // NULL, or the order in which the work items of a cursor shard are handed out (k_order_items): [n_items]
+    const uint32_t* item_list; // NULL, or the order in which the LAST order_window work items of every cursor shard are handed out
+                               // (k_order_items): [ITEM_SHARDS][order_window]
+    uint32_t order_window;
+    FastDiv items_per_shard_div;
 };
 
 struct TParams {
@@ -1361,7 +1364,12 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         }
         if (item == ITEM_NONE) item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
         if (item == ITEM_NONE) return false;
-        if (P.item_list) item = P.item_list[item]; // (small launches: paths that stop at their first vertex last, k_order_items)
+        if (P.item_list) { // the tail of every cursor shard is handed out "paths that stop at their first vertex last" (k_order_items)
+            const uint32_t sh_ = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh);
+            const uint32_t slo_ = sh_ * P.items_per_shard, shi_ = min(slo_ + P.items_per_shard, P.n_items);
+            const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
+            if (item >= wlo_) item = P.item_list[sh_ * P.order_window + (item - wlo_)];
+        }
         bool valid; uint32_t pi, pj, pixel_index, k;
         decode_item(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
@@ -2114,22 +2122,24 @@ __device__ __forceinline__ FastDiv make_fastdiv_dev(uint32_t d)
     return f;
 }
 
-// Orders the work items of every cursor shard: first the paths whose roulette draw lets them continue past their first vertex, then
-// the ones it stops there (and the padding slots of ragged tiles).  The draws are addressed (crt_detmath.h), so this is known before
+// Orders the LAST order_window work items of every cursor shard (what the waves are handed when a launch ends): first the paths whose
+// roulette draw lets them continue past their first vertex, then the ones it stops there (and the padding slots of ragged tiles).  The draws are addressed (crt_detmath.h), so this is known before
 // anything is traced; the order of the work items cannot change a result (every path writes its own L[item]).  Why: every launch ends
 // with each wave running its pool dry, and the time that takes is the longest path started last -- with one-vertex paths at the
 // end of every shard the fixed cost of a launch drops from 2.5 ms to about 1 ms (tools/share_probe.py: a rank's share of C2 at 1 / 2 / 4 /
-// 8 ranks 106.2 / 54.2 / 28.1 / 15.7 ms without, 105.7 / 53.3 / 27.1 / 14.4 ms with, this pass included).  One wave orders a span of
+// 8 ranks 107.3 / 54.9 / 28.4 / 15.9 ms without, 106.8 / 54.1 / 27.5 / 14.6 ms with, this pass included).  One wave orders a span of
 // 1 024 items of one shard with two atomics (a cache line per counter).
 __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* list, unsigned int* cnt)
 {
-    const uint32_t spans = (P.items_per_shard + 1023u) / 1024u;
+    const uint32_t spans = (P.order_window + 1023u) / 1024u;
     const uint32_t sh = blockIdx.x / spans, sp = blockIdx.x - sh * spans;
-    const uint32_t lo = sh * P.items_per_shard;
-    if (lo >= P.n_items) return;
-    const uint32_t hi = min(lo + P.items_per_shard, P.n_items);
+    const uint32_t slo = sh * P.items_per_shard;
+    if (slo >= P.n_items) return;
+    const uint32_t hi = min(slo + P.items_per_shard, P.n_items);
+    const uint32_t lo = hi - min(P.order_window, hi - slo); // the window: the last order_window items of the shard
     const uint32_t b = lo + sp * 1024u;
     if (b >= hi) return;
+    uint32_t* out = list + (size_t)sh * P.order_window; // out[k] = the item handed out in place of item lo + k
     const uint32_t lane = threadIdx.x;
     uint32_t goes_on = 0, exists = 0; // bit j: item b + 64 j + lane
 #pragma unroll 1
@@ -2156,14 +2166,15 @@ __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* l
     }
     base_on = (unsigned int)__builtin_amdgcn_readfirstlane((int)base_on);
     base_off = (unsigned int)__builtin_amdgcn_readfirstlane((int)base_off);
+    const uint32_t wn = hi - lo;
 #pragma unroll 1
     for (uint32_t j = 0; j < 16; j++) {
         const bool on_j = (goes_on >> j) & 1u, ex_j = (exists >> j) & 1u;
         const unsigned long long m_on = __ballot(on_j), m_off = __ballot(ex_j && !on_j);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t i = b + j * 64u + lane;
-        if (on_j) list[lo + base_on + (uint32_t)__popcll(m_on & below)] = i;
-        else if (ex_j) list[hi - 1u - (base_off + (uint32_t)__popcll(m_off & below))] = i;
+        if (on_j) out[base_on + (uint32_t)__popcll(m_on & below)] = i;
+        else if (ex_j) out[wn - 1u - (base_off + (uint32_t)__popcll(m_off & below))] = i;
         base_on += (unsigned int)__popcll(m_on);
         base_off += (unsigned int)__popcll(m_off);
     }
@@ -2771,10 +2782,15 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     const char* eo = std::getenv("CRT_ITEM_ORDER");
                     const bool order = !(eo && eo[0] == '0');
                     if (order && P.n_items > 0) {
-                        sc->item_list.ensure(P.n_items);
+                        // the window: the last 2^20 work items of every shard (measured on C2, wall time of a rank's share at 1 / 2 / 4 / 8 ranks: no
+                        // order 107.3 / 54.9 / 28.4 / 15.9 ms; 2^17: 107.4 / 54.5 / 28.3 / 15.2; 2^19: 106.8 / 54.2 / 27.7 / 14.6; whole shards:
+                        // 107.2 / 54.1 / 27.5 / 14.6 -- the pass itself costs 0.9 ms for the 245.8 M items of a whole frame)
+                        P.order_window = std::min<uint32_t>(P.items_per_shard, env_u32("CRT_ORDER_WINDOW", 1u << 20));
+                        P.items_per_shard_div = make_fastdiv(std::max(1u, P.items_per_shard));
+                        sc->item_list.ensure((size_t)ITEM_SHARDS * P.order_window);
                         sc->order_cnt.ensure((size_t)ITEM_SHARDS * 2 * 32);
                         HIP_CHECK(hipMemsetAsync(sc->order_cnt.p, 0, (size_t)ITEM_SHARDS * 2 * 32 * sizeof(unsigned int), st));
-                        const uint32_t spans = (P.items_per_shard + 1023u) / 1024u;
+                        const uint32_t spans = (P.order_window + 1023u) / 1024u;
                         hipLaunchKernelGGL(k_order_items, dim3(ITEM_SHARDS * spans), dim3(64), 0, st, P, sc->item_list.p, sc->order_cnt.p);
                         HIP_CHECK(hipGetLastError());
                         P.item_list = sc->item_list.p;
