@@ -2782,10 +2782,10 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     const char* eo = std::getenv("CRT_ITEM_ORDER");
                     const bool order = !(eo && eo[0] == '0');
                     if (order && P.n_items > 0) {
-                        // the window: the last 2^20 work items of every shard (measured on C2, wall time of a rank's share at 1 / 2 / 4 / 8 ranks: no
+                        // the window: the last 2^19 work items of every shard (measured on C2, wall time of a rank's share at 1 / 2 / 4 / 8 ranks: no
                         // order 107.3 / 54.9 / 28.4 / 15.9 ms; 2^17: 107.4 / 54.5 / 28.3 / 15.2; 2^19: 106.8 / 54.2 / 27.7 / 14.6; whole shards:
                         // 107.2 / 54.1 / 27.5 / 14.6 -- the pass itself costs 0.9 ms for the 245.8 M items of a whole frame)
-                        P.order_window = std::min<uint32_t>(P.items_per_shard, env_u32("CRT_ORDER_WINDOW", 1u << 20));
+                        P.order_window = std::min<uint32_t>(P.items_per_shard, env_u32("CRT_ORDER_WINDOW", 1u << 19));
                         P.items_per_shard_div = make_fastdiv(std::max(1u, P.items_per_shard));
                         sc->item_list.ensure((size_t)ITEM_SHARDS * P.order_window);
                         sc->order_cnt.ensure((size_t)ITEM_SHARDS * 2 * 32);
