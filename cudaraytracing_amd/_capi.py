@@ -114,6 +114,8 @@ TRI_DTYPE = np.dtype([("v1", "<f4", 3), ("v2", "<f4", 3), ("v3", "<f4", 3), ("no
 MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3), ("ns", "<f4"), ("mode", "<i4"), ("has_emit", "<i4")])
 LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
+ABI_VERSION = 3  # include/crt.h: CRT_ABI_VERSION
+
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
            "crt_scene_accel_info", "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
@@ -136,6 +138,9 @@ def lib():
         return _lib
     path = _build.build_lib()
     L = C.CDLL(path)
+    L.crt_abi_version.restype = C.c_int
+    if L.crt_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s speaks ABI version %d, these bindings version %d (include/crt.h: CRT_ABI_VERSION)" % (path, L.crt_abi_version(), ABI_VERSION))
     L.crt_strerror.restype = C.c_char_p
     L.crt_strerror.argtypes = [C.c_int]
     L.crt_last_error.restype = C.c_char_p

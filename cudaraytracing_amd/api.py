@@ -168,8 +168,15 @@ class Render:
         self.mean_buffer = None
         self.stats = None
 
+    def _handle(self, what):
+        """The crt_scene* of this renderer; raises when there is none (freed, or a MultiRender, whose handle is a crt_multi*)."""
+        if not self._h:
+            raise RuntimeError("%s: no single-device scene handle (freed, or a MultiRender)" % what)
+        return self._h
+
     def accel_info(self):
         """How the acceleration trees of the FAST traversal were built (crt_scene_accel_info)."""
+        self._handle("accel_info")
         a = capi.AccelInfo()
         capi.check(capi.lib().crt_scene_accel_info(self._h, C.byref(a)), "crt_scene_accel_info")
         return a.as_dict()
@@ -233,7 +240,7 @@ class Render:
         """(device ms, launches) of the render kernel of the last frame submitted on this handle (crt_last_launch_ms); the frame's
         stream must have been synchronized."""
         ms, n = C.c_float(), C.c_uint32()
-        capi.check(capi.lib().crt_last_launch_ms(self._h, C.byref(ms), C.byref(n)), "crt_last_launch_ms")
+        capi.check(capi.lib().crt_last_launch_ms(self._handle("last_launch_ms"), C.byref(ms), C.byref(n)), "crt_last_launch_ms")
         return float(ms.value), int(n.value)
 
     def preview(self, want_mean=False, width=None, height=None):
@@ -251,6 +258,7 @@ class Render:
     def run_view_device(self, eye_pos, inv_view_mat, fovY, d_rgb_ptr, d_mean_ptr=None, stream=None, rank=0, world=1,
                         tiled=False, want_stats=True, width=None, height=None):
         """Enqueues a render whose outputs stay in device memory (raw device pointers)."""
+        self._handle("run_view_device")
         cam = self._cam(eye_pos, inv_view_mat, fovY)
         flags = (capi.FLAG_TILED_OUTPUT if (tiled or world > 1) else 0) | self.extra_flags
         prm = self._params(rank=rank, world=world, flags=flags, width=width, height=height)
@@ -264,6 +272,7 @@ class Render:
         return self.stats
 
     def intersect(self, origins, dirs, traversal=None):
+        self._handle("intersect")
         o = np.ascontiguousarray(origins, dtype=np.float32)
         d = np.ascontiguousarray(dirs, dtype=np.float32)
         n = o.shape[0]
@@ -276,6 +285,7 @@ class Render:
 
     def blocked(self, origins, dirs, limits, traversal=None):
         """blocked() of Render.cuh:19-27 for n visibility rays with t_to_light = limits: (blocked, blocking triangle or -1)"""
+        self._handle("blocked")
         o = np.ascontiguousarray(origins, dtype=np.float32)
         d = np.ascontiguousarray(dirs, dtype=np.float32)
         n = o.shape[0]
@@ -320,9 +330,10 @@ class MultiRender(Render):
         self.extra_flags = 0
         self.devices = [int(d) for d in devices]
         self.device = self.devices[0]
-        self._h = C.c_void_p()
+        self._h = C.c_void_p()   # stays null: every inherited method that takes a crt_scene* fails its own check
+        self._mh = C.c_void_p()  # the crt_multi*
         devs = (C.c_int * len(self.devices))(*self.devices)
-        capi.check(capi.lib().crt_multi_create(C.byref(scene.desc()), devs, len(self.devices), gather, C.byref(self._h)),
+        capi.check(capi.lib().crt_multi_create(C.byref(scene.desc()), devs, len(self.devices), gather, C.byref(self._mh)),
                    "crt_multi_create")
         self.frame_buffer = None
         self.mean_buffer = None
@@ -331,7 +342,7 @@ class MultiRender(Render):
         self.info = None
 
     def run_view(self, eye_pos, inv_view_mat, fovY, stats=False, want_mean=True, width=None, height=None, to_host=True):
-        if not self._h:
+        if not self._mh:
             raise RuntimeError("MultiRender.run_view after free()")
         cam = self._cam(eye_pos, inv_view_mat, fovY)
         prm = self._params(flags=(capi.FLAG_STATS if stats else 0) | self.extra_flags, width=width, height=height)
@@ -340,7 +351,7 @@ class MultiRender(Render):
         mean = np.zeros((h, w, 3), dtype=np.float32) if (want_mean and to_host) else None
         st = (capi.Stats * len(self.devices))()
         info = capi.MultiInfo()
-        capi.check(capi.lib().crt_multi_render(self._h, C.byref(cam), C.byref(prm), capi.ptr(rgb), capi.ptr(mean), st,
+        capi.check(capi.lib().crt_multi_render(self._mh, C.byref(cam), C.byref(prm), capi.ptr(rgb), capi.ptr(mean), st,
                                                C.byref(info)), "crt_multi_render")
         self.rank_stats = [s.as_dict() for s in st]
         self.info = info.as_dict()
@@ -370,10 +381,16 @@ class MultiRender(Render):
     def intersect(self, *a, **k):
         raise NotImplementedError("crt_intersect is a single-device interface")
 
+    def blocked(self, *a, **k):
+        raise NotImplementedError("crt_intersect is a single-device interface")
+
+    def last_launch_ms(self):
+        raise NotImplementedError("crt_last_launch_ms is a single-device interface (per-rank kernel times: rank_stats)")
+
     def free(self):
-        if self._h:
-            capi.lib().crt_multi_destroy(self._h)
-            self._h = C.c_void_p()
+        if self._mh:
+            capi.lib().crt_multi_destroy(self._mh)
+            self._mh = C.c_void_p()
 
 
 def image_load(path):

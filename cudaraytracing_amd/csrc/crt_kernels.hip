@@ -988,6 +988,8 @@ struct MParams3 {
     int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
 };
 
+static_assert(offsetof(MParams3, dbg_loads) == 588 && offsetof(MParams3, dbg_valu) == 592, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
+
 struct NewRay {
     F3 o, d;
     float tl;
@@ -2594,6 +2596,50 @@ Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16)
     if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, false, false, true> : (Mega3Kernel)k_mega3<0, true, false, false, false>;
     return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true> : (Mega3Kernel)k_mega3<0, false, false, false, false>;
 }
+// Diagnostic hook (tools/bbprof): CRT_BBPROF_CO names a code object holding the default instantiation of k_mega3 with a counting
+// prologue in every basic block (tools/bbprof/instrument.py applied to the compiler's assembly of THIS file); the launch then goes
+// to that copy, the address of its counter buffer travels in MParams3::dbg_loads / dbg_valu, and the summed counters
+// (one u64 per block: executions << 32 | active lanes) are written to CRT_BBPROF_OUT after every launch.  Returns false when the
+// variable is not set or the kernel is another instantiation: the caller launches as usual.
+bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t st)
+{
+    static const char* co = std::getenv("CRT_BBPROF_CO");
+    if (!co || !*co || kern != (Mega3Kernel)k_mega3<2, false, false, false, true>) return false;
+    enum { N_CNT = 4096, STRIDE = 128 };
+    static hipModule_t mod = nullptr;
+    static hipFunction_t fn = nullptr;
+    static char* buf = nullptr;
+    static char* cnt = nullptr;
+    static std::vector<unsigned long long> sum(N_CNT, 0ull);
+    if (!fn) {
+        HIP_CHECK(hipModuleLoad(&mod, co));
+        HIP_CHECK(hipModuleGetFunction(&fn, mod, "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1EEEvNS_8MParams3E"));
+        HIP_CHECK(hipMalloc((void**)&buf, 2 * (size_t)N_CNT * STRIDE));
+        // the prologues add block offsets to the low address word without a carry: the counters must not straddle a 4 GiB boundary
+        cnt = buf;
+        const uint64_t lo = (uint64_t)(uintptr_t)buf & 0xffffffffull;
+        if (lo + (uint64_t)N_CNT * STRIDE > 0x100000000ull) cnt = buf + (0x100000000ull - lo);
+    }
+    HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)N_CNT * STRIDE, st));
+    const uint64_t a = (uint64_t)(uintptr_t)cnt;
+    M3.dbg_loads = (int32_t)(uint32_t)(a & 0xffffffffull);
+    M3.dbg_valu = (int32_t)(uint32_t)(a >> 32);
+    size_t sz = sizeof(M3);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &M3, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIP_CHECK(hipModuleLaunchKernel(fn, blocks, 1, 1, 64, 1, 1, 0, st, nullptr, cfg));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<char> h((size_t)N_CNT * STRIDE);
+    HIP_CHECK(hipMemcpy(h.data(), cnt, h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N_CNT; i++) { unsigned long long v; std::memcpy(&v, h.data() + (size_t)i * STRIDE, 8); sum[i] += v; }
+    if (const char* out = std::getenv("CRT_BBPROF_OUT")) {
+        if (FILE* f = std::fopen(out, "w")) {
+            for (int i = 0; i < N_CNT; i++) if (sum[i]) std::fprintf(f, "%d %llu %llu\n", i, sum[i] >> 32, sum[i] & 0xffffffffull);
+            std::fclose(f);
+        }
+    }
+    return true;
+}
+
 // Which pipeline renders: 4 = k_mega3 (the product), 2 = the wavefront pipeline (k_logic + k_trace).  k_mega3 keeps the best
 // triangle's offset inside its leaf in 16 bits, addresses nodes and leaf records with 32-bit byte offsets and the traversal stack
 // depth in 8 bits; scenes beyond any of these fall back to the wavefront pipeline, which has no such limits.  The CRT_TEST_*
@@ -2808,7 +2854,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
                     if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
                     if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
-                    hipLaunchKernelGGL(kern3, dim3(blocks), dim3(64), 0, st, M3);
+                    if (!bbprof_launch(kern3, M3, blocks, st)) hipLaunchKernelGGL(kern3, dim3(blocks), dim3(64), 0, st, M3);
                 }
                 HIP_CHECK(hipGetLastError());
                 if (s0 + ns >= s_end) HIP_CHECK(hipEventRecord(sc->ev_k1, st));

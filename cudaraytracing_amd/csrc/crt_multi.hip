@@ -15,16 +15,34 @@
 #include "../../include/crt.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
+
+// The handful of RCCL declarations this file needs, restated so that libcrt.so builds on a box without the RCCL headers (the
+// library itself is bound with dlopen below).  Values as in rccl.h / nccl.h: ncclSuccess = 0, ncclUint8 = 1.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1 };
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char* ncclGetErrorString(ncclResult_t result);
+}
 
 extern "C" void crt_set_last_error_(const char* msg);
 
@@ -61,12 +79,16 @@ struct Rccl {
     bool ok = false;
 };
 
+void rccl_load(Rccl& R);
 Rccl& rccl()
 {
     static Rccl R;
-    static bool tried = false;
-    if (tried) return R;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(R); });
+    return R;
+}
+void rccl_load(Rccl& R)
+{
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         R.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -75,11 +97,11 @@ Rccl& rccl()
     if (!R.handle) {
         const char* e = dlerror();
         R.error = std::string("cannot load librccl.so.1: ") + (e ? e : "?");
-        return R;
+        return;
     }
 #define SYM(field, name)                                                      \
     R.field = (decltype(R.field))dlsym(R.handle, name);                       \
-    if (!R.field) { R.error = std::string("librccl: missing symbol ") + name; return R; }
+    if (!R.field) { R.error = std::string("librccl: missing symbol ") + name; return; }
     SYM(GetVersion, "ncclGetVersion")
     SYM(CommInitAll, "ncclCommInitAll")
     SYM(CommDestroy, "ncclCommDestroy")
@@ -90,8 +112,14 @@ Rccl& rccl()
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     R.ok = true;
-    return R;
 }
+
+// Restores the calling thread's current device on every way out (the entry points walk over the ranks' devices).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
 
 struct NcclErr {
     ncclResult_t r;
@@ -145,6 +173,7 @@ struct crt_multi {
     uint8_t* frame = nullptr;  // rank 0: row-major RGB8
     float* mean = nullptr;     // rank 0: row-major mean
     size_t frame_cap = 0, mean_cap = 0;
+    bool last_had_mean = false; // the last crt_multi_render wrote `mean`
 };
 
 namespace {
@@ -195,8 +224,10 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
     }
     if (gather == CRT_GATHER_RCCL && !distinct) return mfail(CRT_ERR_INVALID_ARG, "crt_multi_create: RCCL needs one rank per device (duplicate device index)");
     if (gather == CRT_GATHER_AUTO) gather = (distinct && n_devices > 1) ? CRT_GATHER_RCCL : CRT_GATHER_COPY;
-    crt_multi* m = new crt_multi();
+    DeviceGuard guard;
+    crt_multi* m = nullptr;
     try {
+        m = new crt_multi();
         m->gather = gather;
         m->ranks.resize(n_devices);
         for (uint32_t r = 0; r < n_devices; r++) {
@@ -263,6 +294,13 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
     const bool want_mean = out_mean != nullptr;
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
+    DeviceGuard guard;
+    // an error must not leave work in flight on buffers the next call may free or reallocate
+    auto drain = [&]() {
+        for (Rank& rk : m->ranks)
+            if (hipSetDevice(rk.device) == hipSuccess && rk.stream) (void)hipStreamSynchronize(rk.stream);
+    };
+    m->last_had_mean = false;
     try {
         uint64_t slots = 0;
         int rc = crt_shard_slots(prm->width, prm->height, 0, world, &slots);
@@ -279,7 +317,12 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
         {
             size_t fb = (size_t)prm->width * prm->height * 3;
             ensure(m->frame, m->frame_cap, fb);
-            if (want_mean) { uint8_t* p = (uint8_t*)m->mean; ensure(p, m->mean_cap, fb * 4); m->mean = (float*)p; }
+            if (want_mean) { // (through a local: the member must never hold a freed pointer if the allocation throws)
+                uint8_t* p = (uint8_t*)m->mean;
+                m->mean = nullptr;
+                ensure(p, m->mean_cap, fb * 4);
+                m->mean = (float*)p;
+            }
         }
         // ---- every rank renders its tiles: one host thread per device, each on its own stream ----
         std::vector<int> rcs(world, CRT_OK);
@@ -301,7 +344,7 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
             for (std::thread& t : th) t.join();
         }
         for (uint32_t r = 0; r < world; r++)
-            if (rcs[r] != CRT_OK) return mfail(rcs[r], "crt_multi_render: rank " + std::to_string(r) + ": " + errs[r]);
+            if (rcs[r] != CRT_OK) { drain(); return mfail(rcs[r], "crt_multi_render: rank " + std::to_string(r) + ": " + errs[r]); }
         const auto t1 = clk::now();
         // ---- one exchange: all-gather of the compact tile blocks ----
         if (m->gather == CRT_GATHER_RCCL) {
@@ -341,6 +384,7 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
             MHIP(hipStreamSynchronize(m->ranks[r].stream));
         }
         const auto t2 = clk::now();
+        m->last_had_mean = want_mean;
         if (stats) std::memcpy(stats, st.data(), sizeof(crt_stats) * world);
         if (info) {
             std::memset(info, 0, sizeof(*info));
@@ -359,10 +403,13 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
         }
         return CRT_OK;
     } catch (const HipErr& f) {
+        drain();
         return mfail(CRT_ERR_HIP, std::string("crt_multi_render: ") + f.what + ": " + hipGetErrorString(f.e));
     } catch (const NcclErr& f) {
+        drain();
         return mfail(CRT_ERR_HIP, std::string("crt_multi_render: ") + f.what + ": " + rccl().GetErrorString(f.r));
     } catch (const std::bad_alloc&) {
+        drain();
         return mfail(CRT_ERR_OOM, "crt_multi_render: out of host memory");
     }
 }
@@ -371,7 +418,7 @@ int crt_multi_frame_device(crt_multi* m, void** d_rgb, void** d_mean, int* devic
 {
     if (!m) return mfail(CRT_ERR_INVALID_ARG, "crt_multi_frame_device: null argument");
     if (d_rgb) *d_rgb = m->frame;
-    if (d_mean) *d_mean = m->mean;
+    if (d_mean) *d_mean = m->last_had_mean ? m->mean : nullptr;
     if (device) *device = m->ranks[0].device;
     return CRT_OK;
 }

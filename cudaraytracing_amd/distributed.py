@@ -124,14 +124,23 @@ class FramePipeline:
         # different queues, so the two frames in flight alternate between a normal and a high-priority stream.
         self.streams = [torch.cuda.Stream(device=device, priority=(0 if k % 2 == 0 else -1)) for k in range(len(self.renders))]
         self.pending = [None] * len(self.renders)   # per handle: image tensor of the frame in flight
+        self.ready = [None] * len(self.renders)     # per handle: event recorded behind the frame's last operation (the de-interleave that follows the gather)
         self.next = 0
         self.done = []
         self.kernel_ms = []
 
     def _retire(self, h):
         if self.pending[h] is not None:
+            # The all-gather runs on ProcessGroupNCCL's own stream; the synchronous call makes the frame's stream wait for it, and the
+            # de-interleave that produces the image is enqueued on the frame's stream behind that wait.  The event recorded after it is
+            # what publishing the image waits for.
+            if self.ready[h] is not None:
+                self.ready[h].synchronize()
             self.streams[h].synchronize()
-            ms, _ = self.renders[h].last_launch_ms()
+            try:
+                ms, _ = self.renders[h].last_launch_ms()
+            except Exception:   # the wavefront fallback pipeline records no megakernel launch
+                ms = None
             self.kernel_ms.append(ms)
             self.done.append(self.pending[h])
             self.pending[h] = None
@@ -150,6 +159,9 @@ class FramePipeline:
             self.renders[h].run_view_device(eye, inv_view, fov_y, local.data_ptr(), None, s.cuda_stream, rank=rank, world=world, tiled=True,
                                             want_stats=False, width=width, height=height)
             self.pending[h] = gather_image(local, width, height, world, group)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self.ready[h] = ev
 
     def drain(self):
         for k in range(len(self.renders)):

@@ -24,7 +24,11 @@
 extern "C" {
 #endif
 
-#define CRT_ABI_VERSION 2
+/* 3: CRT_TRAVERSAL_* renumbered (0 = EXACT, the default of a zeroed crt_params; FAST moved to 2), crt_intersect's `traversal`
+ *    argument carries flag bits (CRT_INTERSECT_RAW_DIRECTIONS 0x100, _FORCE_EXACT 0x200, _VISIBILITY 0x400), progressive /
+ *    preview / multi-device / accel-info entry points and structs added.  A client built against version 2 must be rebuilt:
+ *    check crt_abi_version() == CRT_ABI_VERSION at load time. */
+#define CRT_ABI_VERSION 3
 
 typedef enum {
     CRT_OK = 0,

@@ -59,7 +59,7 @@ def test_ranks_on_one_device_reproduce_the_single_device_frame(single, name, w, 
         rgb5 = one.run_view(eye, iv, fov, width=w, height=h).copy()
         one.seed = 0
         d_rgb, d_mean, dev = C.c_void_p(), C.c_void_p(), C.c_int(-1)
-        capi.check(capi.lib().crt_multi_frame_device(m._h, C.byref(d_rgb), C.byref(d_mean), C.byref(dev)), "crt_multi_frame_device")
+        capi.check(capi.lib().crt_multi_frame_device(m._mh, C.byref(d_rgb), C.byref(d_mean), C.byref(dev)), "crt_multi_frame_device")
         assert dev.value == 0 and d_rgb.value
         m.seed = 5
         assert np.array_equal(m.run_view(eye, iv, fov, width=w, height=h), rgb5)
