@@ -136,7 +136,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build_lib()
+    path = os.environ.get("CRT_LIB_PATH") or _build.build_lib()  # (CRT_LIB_PATH: an A/B build of the library, tools/ab.sh)
     L = C.CDLL(path)
     L.crt_abi_version.restype = C.c_int
     if L.crt_abi_version() != ABI_VERSION:

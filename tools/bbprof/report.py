@@ -25,8 +25,8 @@ def phase_ranges():
     """Line ranges of the phase arms of k_mega3's main loop, found by their markers in the source."""
     lines = open(os.path.join(SRC, "crt_kernels.hip")).read().split("\n")
     k0 = next(i for i, l in enumerate(lines) if "void k_mega3(const MParams3 M3)" in l) + 1
-    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"if \(act == PH3_INNER\) \{"), ("leaf", r"else if \(act == PH3_LEAF\) \{"),
-             ("LA", r"else if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"^\s*\} else \{\s*$"), ("end", r"^#undef PUSH3")]
+    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"if \(act == PH3_INNER\) \{"), ("leaf", r"leaf step: the record.s two triangles"),
+             ("LA", r"if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"^\s*\} else \{\s*$"), ("end", r"^#undef PUSH3")]
     at, cur = [], k0
     for name, pat in marks:
         while not re.search(pat, lines[cur]):
