@@ -1043,6 +1043,14 @@ __device__ __forceinline__ float rcp_ieee(const float x)
     return r;
 }
 
+// max of two wave-uniform integers on the scalar unit
+__device__ __forceinline__ int smax(const int a, const int b)
+{
+    int r;
+    asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+}
+
 // Ring index in [0, 2 * POOL3_QCAP) -> [0, POOL3_QCAP).
 __device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)POOL3_QCAP); }
 
@@ -1842,17 +1850,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #endif
 
     for (;;) {
+      int act;
+      // The traversal steps -- nine of ten iterations -- are a loop of their own inside the scheduler loop: the register allocator
+      // weighs a value by the depth of the loops that use it, and with all five phases at one depth it kept the (cold) inner loops of
+      // the logic phases in registers and spilled the ring cursors and node pointers of the traversal steps (19 vector instructions
+      // of spill / copy code per iteration: C2 106.6 -> 99.0 ms, veach-mis 99.4 -> 92.4 ms at spp 256).
+      for (;;) {
         // ---- choose a phase: the ring with the fullest batch; among equals the logic phases first (they feed the traversal), then
         //      leaves, then inner nodes ----
-        int act;
         {
             // key = batch size * 8 + phase number (the phase numbers are the tie-break order)
             const int kC = min(qn[PH3_LC], 64) * 8 + PH3_LC, kA = min(qn[PH3_LA], 64) * 8 + PH3_LA, kB = min(qn[PH3_LB], 64) * 8 + PH3_LB;
             const int kL = min(qn[PH3_LEAF], 64) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
-            const int best = max(max(max(kC, kA), max(kB, kL)), kI);
-            if (best < 8) break; // every ray of the pool is dead
-            act = best & 7;
+            // (s_max_i32 by hand: the compiler folds nested maxima of wave-uniform values into v_max3_i32 -- a vector instruction, plus
+            // two moves in and a v_readfirstlane back)
+            const int best = smax(smax(smax(kC, kA), smax(kB, kL)), kI);
+            act = best < 8 ? PH3_NONE : (best & 7); // (best < 8: every ray of the pool is dead)
         }
+        if (act > PH3_LEAF) break;
         CRT_STAMP3(PH3_N)
 #ifdef CRT_STAMPS
         dg_iter[act]++;
@@ -1923,7 +1938,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             PUSH_TRAV()
             CRT_SEC3(5, nph)
-        } else if (act == PH3_LEAF) {
+        } else {
             // ---- leaf step: the record's two triangles in one packed computation ----
             POP3(PH3_LEAF)
 #ifdef CRT_STAMPS
@@ -1997,7 +2012,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 t_done = done; t_ref = ref; t_flags = qd;
             }
             PUSH_TRAV()
-        } else if (act == PH3_LA) {
+        }
+        CRT_STAMP3(act)
+      }
+        if (act == PH3_NONE) break;
+        CRT_STAMP3(PH3_N)
+#ifdef CRT_STAMPS
+        dg_iter[act]++;
+#endif
+        if (act == PH3_LA) {
             POP3(PH3_LA)
 #ifdef CRT_STAMPS
             dg_lanes[PH3_LA] += (unsigned)take;
