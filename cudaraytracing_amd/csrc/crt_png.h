@@ -1,7 +1,7 @@
 // cudaraytracing_amd/csrc/crt_png.h -- minimal PNG reader for map_Kd textures (host layer).
 //
 // The reference loads textures with stb_image (`stbi_load(path, &x, &y, &comp, 0)`, Loader.h:58), which is
-// not part of this build.  This header decodes what the texture path needs: non-interlaced PNG of colour type
+// not part of this build.  This header decodes what the texture path needs: PNG (plain or Adam7-interlaced) of colour type
 // 0 / 2 / 3 / 4 / 6, bit depth 8 (16: the high byte, as stb does; 1 / 2 / 4: palette and greyscale), with the
 // component count stb would report for req_comp = 0 (grey 1, grey+alpha 2, RGB 3, RGBA 4; palette 3, or 4 with a
 // tRNS chunk; a tRNS colour key adds an alpha component).  Other formats are reported as unsupported.
@@ -196,7 +196,7 @@ inline std::string load(const std::string& path, Image& img)
         pos += 12 + (size_t)len;
     }
     if (ctype < 0 || w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24)) return "bad PNG header in " + path;
-    if (interlace) return "interlaced PNG is not supported: " + path;
+    if (interlace > 1) return "bad PNG interlace method in " + path;
     int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!chans) return "bad PNG colour type in " + path;
     const bool small = depth == 1 || depth == 2 || depth == 4;
@@ -205,34 +205,49 @@ inline std::string load(const std::string& path, Image& img)
     if (idat.size() < 6) return "PNG without image data: " + path;
     std::vector<uint8_t> raw;
     if (!inflate(idat.data() + 2, idat.size() - 2, raw)) return "corrupt PNG data stream in " + path; // 2-byte zlib header
-    const size_t bpp_bits = (size_t)chans * depth, stride = (w * bpp_bits + 7) / 8, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
-    if (raw.size() < (stride + 1) * h) return "short PNG data stream in " + path;
-    std::vector<uint8_t> cur(stride), prev(stride, 0), lines((size_t)stride * h);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* s = &raw[(stride + 1) * y];
-        const int ft = s[0];
-        if (ft > 4) return "bad PNG filter in " + path;
-        for (size_t x = 0; x < stride; x++) {
-            int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0, v = s[1 + x];
-            switch (ft) {
-            case 1: v += a; break;
-            case 2: v += b; break;
-            case 3: v += (a + b) >> 1; break;
-            case 4: v += paeth(a, b, c); break;
-            default: break;
+    const size_t bpp_bits = (size_t)chans * depth, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    // raw sample values (up to 16 bits) of the whole image, samp[(y * w + x) * chans + c]: filled pass by pass.  A non-interlaced
+    // file is one pass over every pixel; an Adam7 file (stb_image.h:5116-5150 reads them too) is seven reduced images, each with
+    // its own filtered scan lines, whose pixels land at (x0 + i * dx, y0 + j * dy).
+    std::vector<uint16_t> samp((size_t)w * h * chans);
+    static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t rp = 0;
+    for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
+        const uint32_t x0 = interlace ? ax0[pass] : 0, y0 = interlace ? ay0[pass] : 0, dx = interlace ? adx[pass] : 1, dy = interlace ? ady[pass] : 1;
+        const uint32_t pw = (w + dx - 1 - x0) / dx, ph = (h + dy - 1 - y0) / dy;
+        if (x0 >= w || y0 >= h || pw == 0 || ph == 0) continue; // an empty pass has no bytes in the stream
+        const size_t stride = (pw * bpp_bits + 7) / 8;
+        if (raw.size() < rp + (stride + 1) * ph) return "short PNG data stream in " + path;
+        std::vector<uint8_t> cur(stride), prev(stride, 0);
+        for (uint32_t j = 0; j < ph; j++) {
+            const uint8_t* s = &raw[rp + (stride + 1) * j];
+            const int ft = s[0];
+            if (ft > 4) return "bad PNG filter in " + path;
+            for (size_t x = 0; x < stride; x++) {
+                int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0, v = s[1 + x];
+                switch (ft) {
+                case 1: v += a; break;
+                case 2: v += b; break;
+                case 3: v += (a + b) >> 1; break;
+                case 4: v += paeth(a, b, c); break;
+                default: break;
+                }
+                cur[x] = (uint8_t)v;
             }
-            cur[x] = (uint8_t)v;
+            const uint8_t* line = cur.data();
+            uint16_t* o = &samp[((size_t)(y0 + j * dy) * w + x0) * chans];
+            for (uint32_t i = 0; i < pw; i++, o += (size_t)dx * chans)
+                for (int c = 0; c < chans; c++) {
+                    const size_t k = (size_t)i * chans + c;
+                    if (depth == 8) o[c] = line[k];
+                    else if (depth == 16) o[c] = (uint16_t)(line[2 * k] << 8 | line[2 * k + 1]);
+                    else { const int per = 8 / depth; o[c] = (uint16_t)((line[k / per] >> ((per - 1 - (int)(k % per)) * depth)) & ((1 << depth) - 1)); }
+                }
+            prev = cur;
         }
-        std::memcpy(&lines[(size_t)stride * y], cur.data(), stride);
-        prev = cur;
+        rp += (stride + 1) * ph;
     }
-    // expand to 8 bits per component, then to the component count stb_image reports
-    auto sample = [&](const uint8_t* line, size_t i) -> int { // i-th sample of a scan line, raw value
-        if (depth == 8) return line[i];
-        if (depth == 16) return line[2 * i]; // high byte (stb converts 16 -> 8 the same way)
-        const int per = 8 / depth;
-        return (line[i / per] >> ((per - 1 - (int)(i % per)) * depth)) & ((1 << depth) - 1);
-    };
+    // expand to 8 bits per component (16 -> 8: the high byte, as stb_image converts), then to the component count stb_image reports
     int comp = chans;
     if (ctype == 3) comp = trns.empty() ? 3 : 4;
     else if (!trns.empty() && (ctype == 0 || ctype == 2)) comp = chans + 1;
@@ -240,23 +255,23 @@ inline std::string load(const std::string& path, Image& img)
     img.px.assign((size_t)w * h * comp, 0);
     const int scale = (ctype == 0 && small) ? 255 / ((1 << depth) - 1) : 1;
     for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* line = &lines[(size_t)stride * y];
+        const uint16_t* line = &samp[(size_t)y * w * chans];
         uint8_t* o = &img.px[(size_t)y * w * comp];
         for (uint32_t x = 0; x < w; x++) {
             if (ctype == 3) {
-                int idx = sample(line, x);
+                int idx = line[x];
                 if ((size_t)idx * 3 + 2 >= plte.size()) return "PNG palette index out of range in " + path;
                 o[x * comp + 0] = plte[idx * 3]; o[x * comp + 1] = plte[idx * 3 + 1]; o[x * comp + 2] = plte[idx * 3 + 2];
                 if (comp == 4) o[x * comp + 3] = (size_t)idx < trns.size() ? trns[idx] : 255;
             } else {
                 bool key = !trns.empty() && (ctype == 0 || ctype == 2);
                 for (int c = 0; c < chans; c++) {
-                    int v = sample(line, (size_t)x * chans + c);
+                    const int full = line[(size_t)x * chans + c];
+                    const int v = depth == 16 ? full >> 8 : full;
                     o[x * comp + c] = (uint8_t)(v * scale);
                     if (!trns.empty() && (ctype == 0 || ctype == 2)) {
                         int kv = depth == 16 ? ((trns.size() >= (size_t)2 * c + 2) ? (trns[2 * c] << 8 | trns[2 * c + 1]) : -1)
                                              : ((trns.size() >= (size_t)2 * c + 2) ? trns[2 * c + 1] : -1);
-                        int full = depth == 16 ? (line[2 * ((size_t)x * chans + c)] << 8 | line[2 * ((size_t)x * chans + c) + 1]) : v;
                         if (kv != full) key = false;
                     }
                 }

@@ -6,7 +6,8 @@ oracle/Makefile target ref_probe).  Authoring container only; the fixtures and t
 The files cover what a map_Kd may point at (reference: include/Loader.h:55-105): PNG colour types 0/2/3/4/6 at 8 and 16 bit,
 1/2/4-bit palettes and greys, tRNS keys; BMP with 1/4/8-bit palettes, 16-bit 5-5-5 and 5-6-5 bit fields, 24 bit, 32 bit with and
 without alpha, top-down rows, V4/V5 headers, OS/2 header; TGA types 1/2/3/9/10/11, 15/16/24/32 bit, both origins, colour maps
-with 16/24/32-bit entries."""
+with 16/24/32-bit entries; Adam7-interlaced PNG at every depth; JPEG: baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey,
+CMYK, restart intervals, own Huffman and quantisation tables, sizes around the MCU boundaries, RGB component ids, Adobe transform 0."""
 import json
 import os
 import struct
@@ -165,10 +166,141 @@ def main():
     tga(P("tga_cmap32_idx16.tga"), w, h, 1, 16, flat(lambda y, x: struct.pack("<H", int(idxc[y, x]))),
         cmap=[c + bytes([i * 4]) for i, c in enumerate(cm24)], cmap_bits=32)
     tga(P("tga_cmap16.tga"), w, h, 1, 8, flat(lambda y, x: bytes([idxc[y, x]])), cmap=[struct.pack("<H", int(v)) for v in v16.reshape(-1)[:64]], cmap_bits=16)
+    # ---- interlaced PNG (Adam7; reference: stb_image.h:5116-5150) ----
+    def png_adam7(path, arr, color_type, depth, palette=None, trns=None):
+        """arr: (h, w, channels) integer samples of `depth` bits; written as an Adam7 file with a different filter on every line."""
+        hh, ww, ch = arr.shape
+        bpp = max(1, ch * depth // 8)
+        raw = b""
+        fl = 0
+        for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = arr[y0::dy, x0::dx]
+            if sub.shape[0] == 0 or sub.shape[1] == 0:
+                continue
+            prev = None
+            for row in sub:
+                if depth == 16:
+                    line = row.astype(">u2").tobytes()
+                elif depth == 8:
+                    line = row.astype(np.uint8).tobytes()
+                else:
+                    bits = "".join(format(int(v), "0%db" % depth) for v in row.reshape(-1))
+                    bits += "0" * ((-len(bits)) % 8)
+                    line = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+                ft = fl % 5
+                fl += 1
+                pl = prev if prev is not None else bytes(len(line))
+                out = bytearray()
+                for i, v in enumerate(line):
+                    a = line[i - bpp] if i >= bpp else 0
+                    b = pl[i]
+                    c = pl[i - bpp] if i >= bpp else 0
+                    if ft == 0:
+                        pr = 0
+                    elif ft == 1:
+                        pr = a
+                    elif ft == 2:
+                        pr = b
+                    elif ft == 3:
+                        pr = (a + b) >> 1
+                    else:
+                        pp = a + b - c
+                        pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                        pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                    out.append((v - pr) & 255)
+                raw += bytes([ft]) + bytes(out)
+                prev = line
+
+        def chunk(t, d):
+            return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+        body = chunk(b"IHDR", struct.pack(">IIBBBBB", ww, hh, depth, color_type, 0, 0, 1))
+        if palette is not None:
+            body += chunk(b"PLTE", bytes(palette))
+        if trns is not None:
+            body += chunk(b"tRNS", bytes(trns))
+        with open(path, "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n" + body + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    png_adam7(P("png_adam7_rgb8.png"), rgb, 2, 8)
+    png_adam7(P("png_adam7_rgba8_3x2.png"), np.dstack([rgb, alpha])[:2, :3], 6, 8)          # smaller than a pass period: empty passes
+    png_adam7(P("png_adam7_grey8_1x1.png"), grey[:1, :1, None], 0, 8)
+    png_adam7(P("png_adam7_rgb16.png"), rng.integers(0, 65536, (9, 11, 3)), 2, 16)
+    png_adam7(P("png_adam7_grey4.png"), rng.integers(0, 16, (h, w, 1)), 0, 4)
+    png_adam7(P("png_adam7_grey1.png"), rng.integers(0, 2, (10, 19, 1)), 0, 1)
+    png_adam7(P("png_adam7_palette2_trns.png"), rng.integers(0, 4, (h, w, 1)), 3, 2, palette=[255, 0, 0, 0, 255, 0, 0, 0, 255, 9, 99, 199], trns=[255, 128, 0])
+    png_adam7(P("png_adam7_grey_alpha8.png"), np.dstack([grey, alpha]), 4, 8)
+    Image.fromarray(big, "RGB").save(P("png_adam7_pil_rgb.png"), optimize=True)  # (PIL writes no interlaced files: a plain one of the same data as reference point)
+    # ---- JPEG (PIL / libjpeg writes them; reference: stb_image.h:1960-4070) ----
+    yy, xx = np.mgrid[0:37, 0:51]
+    smooth = np.stack([128 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), (xx * 5 + yy * 3) % 256, 255 - (yy * 6) % 256], axis=2)
+    photo = np.clip(smooth + rng.normal(0, 12, smooth.shape), 0, 255).astype(np.uint8)   # smooth + noise: every coefficient band in use
+    J = lambda name, arr, mode="RGB", **kw: Image.fromarray(arr, mode).save(P(name), "JPEG", **kw)
+    J("jpg_444_q90.jpg", photo, quality=90, subsampling=0)
+    J("jpg_422_q85.jpg", photo, quality=85, subsampling=1)
+    J("jpg_420_q75.jpg", photo, quality=75, subsampling=2)
+    J("jpg_420_q30_opt.jpg", photo, quality=30, subsampling=2, optimize=True)           # own Huffman tables
+    J("jpg_420_q100.jpg", photo, quality=100, subsampling=2)
+    J("jpg_420_q3.jpg", photo, quality=3, subsampling=2)                               # coarse tables: values clamp
+    J("jpg_grey_q80.jpg", photo[:, :, 0], "L", quality=80)
+    J("jpg_grey_prog.jpg", photo[:, :, 1], "L", quality=70, progressive=True)
+    J("jpg_444_prog.jpg", photo, quality=88, subsampling=0, progressive=True)
+    J("jpg_420_prog.jpg", photo, quality=60, subsampling=2, progressive=True)            # DC / AC first and refinement scans, EOB runs
+    J("jpg_422_prog_opt.jpg", photo, quality=92, subsampling=1, progressive=True, optimize=True)
+    J("jpg_420_restart_rows.jpg", photo, quality=80, subsampling=2, restart_marker_rows=1)
+    J("jpg_444_restart_blocks.jpg", photo, quality=80, subsampling=0, restart_marker_blocks=3)
+    J("jpg_420_prog_restart.jpg", photo, quality=80, subsampling=2, progressive=True, restart_marker_blocks=2)
+    for (ww, hh) in ((1, 1), (2, 3), (7, 5), (8, 8), (9, 17), (16, 16), (17, 16), (33, 31)):
+        J("jpg_420_%dx%d.jpg" % (ww, hh), np.ascontiguousarray(photo[:hh, :ww]), quality=85, subsampling=2)
+    J("jpg_422_1x9.jpg", np.ascontiguousarray(photo[:9, :1]), quality=85, subsampling=1)
+    J("jpg_444_random.jpg", rng.integers(0, 256, (24, 40, 3), dtype=np.uint8), quality=95, subsampling=0)   # noise: long codes, large coefficients
+    J("jpg_420_random_q50.jpg", rng.integers(0, 256, (24, 40, 3), dtype=np.uint8), quality=50, subsampling=2)
+    Image.fromarray(photo, "RGB").convert("CMYK").save(P("jpg_cmyk.jpg"), "JPEG", quality=85)             # Adobe APP14, four components
+    q16 = [min(255, 3 + 4 * i) for i in range(64)]
+    J("jpg_444_custom_qtables.jpg", photo, qtables=[q16, [min(255, 5 + 3 * i) for i in range(64)]], subsampling=0)
+    # hand-patched variants of jpg_444_q90.jpg: component ids 'R' 'G' 'B' (stb_image then copies the planes instead of converting),
+    # and the same with the JFIF segment renamed plus an Adobe APP14 segment with transform 0
+    base = open(P("jpg_444_q90.jpg"), "rb").read()
+
+    def patch_ids(b, ids):
+        b = bytearray(b)
+        i = 2
+        while i < len(b):
+            assert b[i] == 0xFF
+            m = b[i + 1]
+            L = (b[i + 2] << 8) | b[i + 3]
+            if m in (0xC0, 0xC1, 0xC2):
+                for k in range(3):
+                    b[i + 10 + 3 * k] = ids[k]
+            if m == 0xDA:
+                for k in range(3):
+                    b[i + 5 + 2 * k] = ids[k]
+                break
+            i += 2 + L
+        return bytes(b)
+    open(P("jpg_444_rgb_ids.jpg"), "wb").write(patch_ids(base, b"RGB"))
+    adobe = b"\xff\xee\x00\x0eAdobe\x00\x64\x00\x00\x00\x00\x00"
+    nojfif = base.replace(b"JFIF\x00", b"JFXX\x00", 1)
+    open(P("jpg_444_adobe_rgb.jpg"), "wb").write(nojfif[:2] + adobe + nojfif[2:])
+    # 4:1:1-like ratios that take the pixel-replication path (h = 4): libjpeg writes them with custom sampling factors
+    try:
+        J("jpg_411.jpg", photo, quality=85, subsampling="4:1:1")
+    except Exception as e:  # PIL versions without that name
+        print("no 4:1:1 fixture:", e, file=sys.stderr)
     # ---- what the reference's decoder says ----
     files = sorted(os.listdir(OUT))
-    out = subprocess.check_output([PROBE] + [os.path.join(OUT, f) for f in files])
-    gold = json.loads(out)
+    import hashlib
+    import tempfile
+    with tempfile.TemporaryDirectory() as dump:
+        out = subprocess.check_output([PROBE] + [os.path.join(OUT, f) for f in files], env=dict(os.environ, STB_PROBE_DUMP=dump))
+        gold = json.loads(out)
+        # the JPEG files in full: no second decoder returns stb_image's samples for them (inverse DCT, upsampling and colour
+        # arithmetic are the decoder's own), so the oracle of the tests is fed from here -- keyed by the SHA-1 of the file
+        full = {}
+        for f in files:
+            if f.endswith(".jpg") and "error" not in gold[f]:
+                g = gold[f]
+                a = np.fromfile(os.path.join(dump, f + ".raw"), dtype=np.uint8).reshape(g["y"], g["x"], g["comp"])
+                full[hashlib.sha1(open(os.path.join(OUT, f), "rb").read()).hexdigest()] = a
+        np.savez_compressed(os.path.join(HERE, "stb_jpeg_samples.npz"), **full)
     bad = {k: v for k, v in gold.items() if "error" in v}
     if bad:
         print("stb_image rejects:", bad, file=sys.stderr)

@@ -1,6 +1,8 @@
 """map_Kd textures (reference: include/Loader.h:55-105, include/OBJLoader.h:184-193): per-triangle kd = mean of the
-texels under the three vertices, with the reference's swapped width / height (Loader.h:58).  The product decodes PNG
-with its own reader (csrc/crt_png.h); the oracle gets the samples from an independent decoder (PIL)."""
+texels under the three vertices, with the reference's swapped width / height (Loader.h:58).  The product decodes PNG, JPEG,
+BMP and TGA with its own readers (csrc/crt_png.h, crt_jpeg.h, crt_image.h), pinned against the reference's stb_image
+(tests/golden/stb_decode.json); the oracle gets the samples from an independent decoder (PIL), or -- JPEG -- from the golden
+samples of the reference's decoder."""
 import os
 
 import numpy as np
@@ -102,12 +104,12 @@ def test_textured_materials_match_oracle(tmp_path, kind, w, h):
 
 def test_png_reader_rejects_what_it_does_not_support(tmp_path):
     obj, mtl = _write_scene(str(tmp_path), "rgb", 8, 8)
-    with open(os.path.join(mtl, "tex.png"), "wb") as f:   # a JPEG signature: stb_image would decode it, this build says unsupported
-        f.write(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    with open(os.path.join(mtl, "tex.png"), "wb") as f:   # a GIF signature: stb_image would decode it, this build says unsupported
+        f.write(b"GIF89a" + b"\0" * 64)
     s = crt.Scene(8, 8)
     with pytest.raises(crt.CrtError) as e:
         s.add_obj(obj, mtl)
-    assert "PNG" in str(e.value)
+    assert "GIF" in str(e.value) and "PNG" in str(e.value)
     os.remove(os.path.join(mtl, "tex.png"))
     with pytest.raises(crt.CrtError):
         crt.Scene(8, 8).add_obj(obj, mtl)
@@ -158,12 +160,14 @@ def _fnv1a64(a):
 
 def test_decoders_match_the_references_own_stb_image():
     """tests/golden/stb_decode.json = what the reference's vendored stb_image.h returns for the fixture files (x, y, comp and
-    every sample, via oracle/ref_probe/stb_probe.c): the product's decoders (PNG, BMP, TGA) must return exactly that, and so must
-    the PIL-based feed of the oracle for the PNG files (16 -> 8-bit reduction, palette / tRNS expansion, channel counts)."""
+    every sample, via oracle/ref_probe/stb_probe.c): the product's decoders (PNG plain and Adam7-interlaced, JPEG baseline and
+    progressive, BMP, TGA) must return exactly that, and so must the feed of the oracle (PIL for the PNG files: 16 -> 8-bit
+    reduction, palette / tRNS expansion, channel counts; the golden samples themselves for the JPEG files)."""
     import json
     gold = json.load(open(os.path.join(util.ROOT, "tests", "golden", "stb_decode.json")))["files"]
-    assert len(gold) >= 40
+    assert len(gold) >= 80
     kinds = set()
+    n_jpg = n_adam7 = 0
     for name, g in sorted(gold.items()):
         path = os.path.join(util.ROOT, "tests", "golden", "textures", name)
         x, y, comp, a = crt.image_load(path)
@@ -171,10 +175,79 @@ def test_decoders_match_the_references_own_stb_image():
         assert _fnv1a64(a) == g["fnv1a64"], name
         assert list(a.reshape(-1)[:24]) == g["head"], name
         kinds.add(name.split("_")[0])
-        if name.endswith(".png"):
+        if name.endswith((".png", ".jpg")):
             px, py, pc, pa = O.stb_like_decode(path)
             assert (px, py, pc) == (g["x"], g["y"], g["comp"]) and _fnv1a64(pa) == g["fnv1a64"], name
-    assert kinds == {"png", "bmp", "tga"}
+        n_jpg += name.endswith(".jpg")
+        n_adam7 += "adam7" in name
+    assert kinds == {"png", "bmp", "tga", "jpg"} and n_jpg >= 30 and n_adam7 >= 8
+
+
+def _use_fixture_texture(d, fixture):
+    """Points the scene of _write_scene at a copy of a fixture file of tests/golden/textures (square ones: the reference swaps
+    width and height, Loader.h:58)."""
+    import shutil
+    ext = fixture.rsplit(".", 1)[1]
+    shutil.copy(os.path.join(util.ROOT, "tests", "golden", "textures", fixture), os.path.join(d, "tex." + ext))
+    os.remove(os.path.join(d, "tex.png"))
+    m = open(os.path.join(d, "t.mtl")).read().replace("tex.png", "tex." + ext)
+    open(os.path.join(d, "t.mtl"), "w").write(m)
+    return os.path.join(d, "tex." + ext)
+
+
+@pytest.mark.parametrize("fixture", ["jpg_420_16x16.jpg", "jpg_420_8x8.jpg", "jpg_420_1x1.jpg"])
+def test_jpeg_textures_feed_the_materials(tmp_path, fixture):
+    """map_Kd pointing at a JPEG file: per-triangle kd as the oracle computes it from the samples the REFERENCE's stb_image returns
+    for that file (golden data), bit for bit."""
+    d = str(tmp_path)
+    obj, mtl = _write_scene(d, "rgb", 16, 16)
+    tex = _use_fixture_texture(d, fixture)
+    x, y, comp, mine = crt.image_load(tex)
+    px, py, pc, ref = O.stb_like_decode(tex)
+    assert (x, y, comp) == (px, py, pc) and comp == 3 and np.array_equal(mine, ref)
+    scene = crt.Scene(32, 24)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(2)
+    osc = O.OracleScene([(obj, mtl)], 2)
+    t1, t2 = scene.triangles(), osc.tris()
+    mats = scene.materials()
+    for k in ("kd", "ke", "ns"):
+        assert np.array_equal(util.bits(mats[k][t1["material"]]), util.bits(t2[k])), k
+    if x > 1:
+        assert len(np.unique(mats["kd"][t1["material"]].round(6), axis=0)) > 10
+
+
+@pytest.mark.parametrize("name", ["jpg_420_q75.jpg", "jpg_420_prog.jpg", "jpg_444_restart_blocks.jpg", "jpg_grey_q80.jpg", "jpg_cmyk.jpg", "png_adam7_rgb8.png", "png_adam7_grey4.png"])
+def test_damaged_jpeg_and_interlaced_png_files_are_decoded_or_rejected(tmp_path, name):
+    """Random damage to valid JPEG / Adam7 PNG files: an image or an error, never an out-of-bounds access or an endless loop."""
+    import random
+    random.seed(13)
+    orig = open(os.path.join(util.ROOT, "tests", "golden", "textures", name), "rb").read()
+    p = str(tmp_path / name)
+    ok = bad = 0
+    for it in range(240):
+        b = bytearray(orig)
+        mode = it % 4
+        if mode == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode == 1:
+            b = b[:random.randrange(1, len(b))]
+        elif mode == 2:
+            i = random.randrange(2, len(b))
+            b[i:i] = bytes(random.randrange(256) for _ in range(random.randint(1, 16)))
+        else:   # marker / length / table bytes near the head of the file
+            i = random.randrange(2, min(len(b) - 4, 400))
+            b[i:i + 2] = random.getrandbits(16).to_bytes(2, "big")
+        with open(p, "wb") as f:
+            f.write(bytes(b))
+        try:
+            x, y, comp, a = crt.image_load(p)
+            assert a.size == x * y * comp and 1 <= comp <= 4
+            ok += 1
+        except crt.CrtError:
+            bad += 1
+    assert ok + bad == 240 and ok > 20 and bad > 20
 
 
 @pytest.mark.parametrize("ext,fmt", [("bmp", "BMP"), ("tga", "TGA")])
@@ -201,8 +274,8 @@ def test_bmp_and_tga_textures_feed_the_materials(tmp_path, ext, fmt):
 
 
 def test_formats_outside_this_build_are_named(tmp_path):
-    """stb_image would also read JPEG, GIF, PSD, PIC, PNM and HDR; this build says which format it met and that it is unsupported."""
-    for magic, name in ((b"\xff\xd8\xff\xe0", "JPEG"), (b"GIF89a", "GIF"), (b"8BPS", "PSD"), (b"P6\n2 2\n255\n", "PNM"), (b"#?RADIANCE\n", "Radiance HDR")):
+    """stb_image would also read GIF, PSD, PIC, PNM and HDR; this build says which format it met and that it is unsupported."""
+    for magic, name in ((b"GIF89a", "GIF"), (b"8BPS", "PSD"), (b"P6\n2 2\n255\n", "PNM"), (b"#?RADIANCE\n", "Radiance HDR")):
         p = str(tmp_path / "t.bin")
         with open(p, "wb") as f:
             f.write(magic + b"\0" * 64)
@@ -245,8 +318,13 @@ def test_damaged_bmp_and_tga_files_are_decoded_or_rejected(tmp_path, name):
 
 
 @pytest.mark.gpu
-def test_textured_scene_renders_like_oracle(tmp_path):
+@pytest.mark.parametrize("fixture", [None, "jpg_420_16x16.jpg"])
+def test_textured_scene_renders_like_oracle(tmp_path, fixture):
+    """A frame of a textured scene (PNG written here / a JPEG fixture whose samples the oracle takes from the reference's own
+    decoder): the mean buffer equals the oracle's bit for bit."""
     obj, mtl = _write_scene(str(tmp_path), "rgb", 16, 16)
+    if fixture:
+        _use_fixture_texture(str(tmp_path), fixture)
     scene = crt.Scene(48, 36)
     scene.add_obj(obj, mtl)
     scene.set_BVH(2)
