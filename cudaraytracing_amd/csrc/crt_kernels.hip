@@ -929,9 +929,16 @@ struct MParams {
 #define ST_NEED 6  /* vertex entered with zero next-event samples: straight to roulette */
 // word D of the ray record: traversal stack depth (bits 0-7), best triangle - first triangle of its leaf (bits 8-23), flags
 #define RF_ANYHIT 0x1000000u   /* traversal stops at the first accepted hit closer than the light */
-#define RF_SHADOW 0x2000000u   /* the ray is a next-event sample ... */
-#define RF_LAST 0x4000000u     /* ... and the last one of its vertex */
-#define RF_PROBE 0x8000000u    /* SPECULAR emitter probe */
+#define RF_SHADOW 0x2000000u   /* (NewRay only) the ray is a next-event sample ... */
+#define RF_LAST 0x4000000u     /* (NewRay only) ... and the last one of its vertex */
+#define RF_PROBE 0x8000000u    /* (NewRay only) SPECULAR emitter probe */
+/* In the RECORD bits 25-26 hold instead where the ray goes once its traversal is over, as phase - PH3_LA: 0 = LA (a next-event sample
+   that is not the last of its vertex, a probe, a closest-hit ray that found a surface), 1 = LB (the last next-event sample), 2 = LC
+   (a closest-hit ray that has found nothing so far).  A closest-hit ray that records a hit clears bit 26 -- LC becomes LA, LA and LB
+   stay -- so the route of a finished ray is two instructions (it was a four-way select over five flag bits, eight). */
+#define RR_ROUTE_SHIFT 25
+#define RR_ROUTE_MASK 0x6000000u
+#define RR_ROUTE_LC_BIT 0x4000000u
 #define RF_EXACT 0x10000000u   /* reference box arithmetic (non-finite operands) */
 #define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
 #define RF_SKIP 0x40000000u    /* (NewRay only) next-event sample with a zero contribution: answered without traversal */
@@ -1057,10 +1064,16 @@ __device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, 
 // Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
 // or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
 template <bool QUERY = false>
-__device__ __forceinline__ uint32_t route_done(uint32_t flags)
+__device__ __forceinline__ uint32_t route_done(uint32_t rec_flags)
 {
     if (QUERY) return PH3_LC;
-    return (flags & RF_SHADOW) ? ((flags & RF_LAST) ? PH3_LB : PH3_LA) : ((flags & (RF_PROBE | RF_HASHIT)) ? PH3_LA : PH3_LC);
+    return ((rec_flags >> RR_ROUTE_SHIFT) & 3u) + (uint32_t)PH3_LA;
+}
+// the route bits of a new ray's record (NewRay flags -> record flags)
+__device__ __forceinline__ uint32_t route_bits(uint32_t nr_flags)
+{
+    const uint32_t r = (nr_flags & RF_SHADOW) ? ((nr_flags & RF_LAST) ? 1u : 0u) : ((nr_flags & RF_PROBE) ? 0u : 2u);
+    return r << RR_ROUTE_SHIFT;
 }
 
 // 1 / d per component (Ray.cuh:14), bit for bit the IEEE quotient: the short reciprocal where it is proven equal (rcp_ieee),
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
     cnt.probe += (nr.flags & RF_PROBE) ? 1u : 0u;
     const F3 inv = inv3_exact(nr.d); // 1 / d (Ray.cuh:14)
-    uint32_t flags = nr.flags & ~RF_SKIP;
+    uint32_t flags = (nr.flags & ~(RF_SKIP | RF_SHADOW | RF_LAST | RF_PROBE)) | route_bits(nr.flags);
     // rays with a zero / denormal direction component can put NaNs into the slab test; they walk the reference
     // topology, whose box tests are the reference's own (crt_accel.h)
     // The 4-wide step (slab_quad_pruned) needs every plane distance (plane - o) * (1/d) of the tree to be FINITE: then no operand of
@@ -1781,43 +1794,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         const bool mine = nph == (uint32_t)p; /* lanes without a ray carry PH3_NONE */                                                                        \
         const unsigned long long m = __ballot(mine);                                                                       \
         if (m) {                                                                                                           \
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); \
-            if (mine) S.ring[p][ring_wrap((uint32_t)(qt[p] + rank))] = (uint8_t)id;                                          \
+            /* slot = tail + number of lanes below this one that go the same way: the tail rides in as mbcnt's addend */      \
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qt[p])); \
+            if (mine) S.ring[p][ring_wrap(slot)] = (uint8_t)id;                                                            \
             const int add = (int)__popcll(m);                                                                              \
             qn[p] += add;                                                                                                  \
             qt[p] += add;                                                                                                  \
             if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
         }                                                                                                                  \
     }
-// the same for ONE ring and an explicit lane predicate
-#define PUSH1(p, cond)                                                                                                     \
-    {                                                                                                                      \
-        const bool mine_ = (cond);                                                                                         \
-        const unsigned long long m_ = __ballot(mine_);                                                                     \
-        if (m_) {                                                                                                          \
-            const int rank_ = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, 0u)); \
-            if (mine_) S.ring[p][ring_wrap((uint32_t)(qt[p] + rank_))] = (uint8_t)id;                                      \
-            const int add_ = (int)__popcll(m_);                                                                            \
-            qn[p] += add_;                                                                                                 \
-            qt[p] += add_;                                                                                                 \
-            if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
-        }                                                                                                                  \
-    }
 // after a traversal step: a ray goes on to an inner node or a leaf, or it is finished -- only then (one wave-uniform test
 // for the three logic rings together) is its route worked out from the flag bits of its record
-#ifdef CRT_PUSH_SPLIT /* measured on C2: 118.6 ms against 116.5 ms for the generic five-ring push -- kept for reference only */
-#define PUSH_TRAV()                                                                                                        \
-    PUSH1(PH3_INNER, on && !t_done && t_ref >= 0)                                                                          \
-    PUSH1(PH3_LEAF, on && !t_done && t_ref < 0)                                                                            \
-    if (__ballot(on && t_done)) {                                                                                          \
-        const uint32_t r_ = route_done<QUERY>(t_flags);                                                                    \
-        PUSH1(PH3_LA, on && t_done && r_ == PH3_LA)                                                                        \
-        PUSH1(PH3_LB, on && t_done && r_ == PH3_LB)                                                                        \
-        PUSH1(PH3_LC, on && t_done && r_ == PH3_LC)                                                                        \
-    }
-#else
 #define PUSH_TRAV() { if (on) nph = t_done ? route_done<QUERY>(t_flags) : (t_ref >= 0 ? PH3_INNER : PH3_LEAF); PUSH3() }
-#endif
 // takes the (up to) 64 oldest rays of ring p
 #define POP3(p)                                                                                                            \
     const int take = min(64, qn[p]);                                                                                       \
@@ -1997,7 +1985,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     left -= 2;
                 }
                 if (STATS) tc.leaf++;
-                if (!any_hit && tri >= 0) qd |= RF_HASHIT;
+                if (!any_hit && tri >= 0) qd = (qd & ~RR_ROUTE_LC_BIT) | RF_HASHIT; // (a surface was found: LC -> LA)
                 if (!done) done = stack_pop_ahead(S, M3, id, g, sp, ref, top, lv);
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
@@ -2060,7 +2048,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         CRT_STAMP3(act)
     }
 #undef PUSH3
-#undef PUSH1
 #undef PUSH_TRAV
 #undef POP3
 #undef LOGIC_PARAMS
