@@ -166,16 +166,7 @@ __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, un
 struct PathCounters {
     uint32_t rays, shadow, probe, paths;
     uint32_t untraced; // next-event samples answered without traversal (contribution exactly zero); counted in rays / shadow too
-#ifdef CRT_STAMPS
-    uint32_t sec[8]; // diagnostic build: wave passes through each logic section and lanes that needed it
-    uint32_t sec_lanes[8];
-#endif
 };
-#ifdef CRT_STAMPS
-#define CRT_SEC(i, cond) { const unsigned long long m_ = __ballot(cond); if (m_) { cnt.sec[i]++; cnt.sec_lanes[i] += (uint32_t)__popcll(m_); } }
-#else
-#define CRT_SEC(i, cond)
-#endif
 
 struct Lane {
     F3 ro, rd, pos, Ld, c, nrm;
@@ -264,9 +255,7 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
     // The recursion is a serial chain, but its loads are not: the records (and material rows) of CRT_FINISH_PF vertices are
     // fetched together, so a chunk costs two memory round trips instead of two per vertex (lanes with fewer vertices re-read
     // vertex 0 and skip the arithmetic).
-#ifndef CRT_FINISH_PF
 #define CRT_FINISH_PF 4
-#endif
     for (int v = deepest - 1; v >= 0; v -= CRT_FINISH_PF) {
         float4 a[CRT_FINISH_PF], fm[CRT_FINISH_PF];
         uint32_t mat[CRT_FINISH_PF];
@@ -307,7 +296,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     bool do_enter = false, do_nee_done = false, do_finish = false, do_new = stage == ST_NEW, do_shadow_setup = false;
     int fin_deepest = -1; bool fin_emissive = false; F3 fin_ke = f3(0.0f, 0.0f, 0.0f);
 
-    CRT_SEC(0, stage == ST_SHADOW) CRT_SEC(1, stage == ST_HIT) CRT_SEC(2, stage == ST_PROBE)
     // ---- phase 1: consume the result of the slot's last ray ----
     if (stage == ST_SHADOW) {
         // visibility of next-event sample q (Render.cuh:19-27, :272-284)
@@ -386,7 +374,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
 
     // ---- phase 2: a new vertex (pos, vtri) at `depth`, reached along s.rd ----
     F3 f_r = f3(0.0f, 0.0f, 0.0f);
-    CRT_SEC(3, do_enter)
     if (do_enter) {
         float4 g = sc.tri_geo[(size_t)s.vtri * 3 + 2];
         s.nrm = f3(g.y, g.z, g.w);
@@ -409,7 +396,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 3: direct light of vertex `depth` is complete: Russian roulette and bounce (Render.cuh:210-228) ----
-    CRT_SEC(4, do_nee_done)
     if (do_nee_done) {
         pl.rec_a[(size_t)s.depth * pl.n + slot] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, 0.0f);
         bool stop = s.depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
@@ -435,7 +421,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 4: path complete ----
-    CRT_SEC(5, do_finish)
     if (do_finish) {
         F3 L = finish_path(P, tb, slot, fin_deepest, fin_emissive, fin_ke);
         P.L[s.item] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -443,7 +428,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 5: take the next work item, camera ray (Render.cuh:344-347) ----
-    CRT_SEC(6, do_new)
     if (do_new) {
         s.stage = ST_DEAD;
         for (;;) {
@@ -472,7 +456,6 @@ __device__ __forceinline__ bool logic_advance(const LParams& P, const Tables<LDS
     }
 
     // ---- phase 6: next-event sample q of the current vertex ----
-    CRT_SEC(7, do_shadow_setup)
     if (do_shadow_setup) {
         setup_shadow(P, tb, s, f_r);
         s.stage = ST_SHADOW;
@@ -956,10 +939,6 @@ static_assert(POOL3_QCAP >= POOL3_P, "a ring must hold every ray of the pool");
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-#ifndef CRT_INV_LDS
-#define CRT_INV_LDS 0 /* 1: 1/direction is part of the ray record (+12 B per ray); 0: the inner step recomputes it from the direction (short exact
-                         reciprocals, +13 instructions per step) -- since the stack entries are 16 bits wide the larger pool pays for them */
-#endif
 #ifndef CRT_WAVES
 #define CRT_WAVES 4   /* waves per SIMD the kernel is compiled for; the LDS footprint of a pool must allow it (160 KiB per CU) */
 #endif
@@ -975,11 +954,7 @@ struct Pool3LdsT {
     typedef typename std::conditional<R16_, short, int>::type stk_t;
     float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
     float4 B[POOL3_P];           // direction.xyz, bits(best triangle, -1 = none)
-#if CRT_INV_LDS
-    float4 C[POOL3_P];           // 1/direction.xyz (Ray.cuh:14), bits(current node ref)
-#else
     int node[POOL3_P];           // current node ref
-#endif
     stk_t stk[LV][POOL3_P];      // traversal stack (node refs); deeper levels spill to global memory
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N][POOL3_QCAP];
@@ -992,7 +967,7 @@ struct MParams3 {
     MParams M;
     int* spill;                  // [level - POOL_LV][pool slot] stack entries beyond the LDS levels
     uint32_t force_exact;        // CRT_FLAG_FORCE_EXACT
-    int32_t dbg_loads, dbg_valu; // -DCRT_STAMPS builds: extra (result-neutral) node loads / VALU chains per inner step, to find the bound
+    int32_t dbg_loads, dbg_valu; // unused by the kernel; tools/bbprof passes the address of its counter buffer in these two dwords
 };
 
 static_assert(offsetof(MParams3, dbg_loads) == 588 && offsetof(MParams3, dbg_valu) == 592, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
@@ -1091,7 +1066,8 @@ __device__ __forceinline__ F3 inv3_exact(const F3 d)
 
 // Writes the new ray into the pool record `id` and returns its first phase.
 template <int MODE, bool QUERY = false, class LDS = Pool3Lds>
-__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact)
+__device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact,
+                                              bool& enters_exact)
 {
     cnt.rays++;
     cnt.shadow += (nr.flags & RF_SHADOW) ? 1u : 0u;
@@ -1120,13 +1096,11 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     }
     S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, T);
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
-#if CRT_INV_LDS
-    S.C[id] = make_float4(inv.x, inv.y, inv.z, __int_as_float(ref));
-#else
     S.node[id] = ref;
-#endif
     S.D[id] = flags;
+    enters_exact = false;
     if (answered) return route_done<QUERY>(flags);
+    enters_exact = MODE != 1 && (flags & RF_EXACT) != 0; // (counted by the caller: the traversal steps of a pool without such rays skip their handling)
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
 }
 
@@ -1349,16 +1323,13 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
     // The next work item is asked for NOW -- one atomic on the wave's home cursor for all its lanes -- and looked at after the
     // backward recursion: the cursor's round trip hides behind the recursion's own loads (the earlier attempt read the answer with
     // a readfirstlane at once, which waits).  A home shard that has run dry (the end of a launch) falls back to grab_item below.
-#ifndef CRT_GRAB_AHEAD
-#define CRT_GRAB_AHEAD 1
-#endif
     const uint32_t home_ = blockIdx.x & (ITEM_SHARDS - 1);
     const uint32_t lo_ = home_ * P.items_per_shard, hi_ = min(lo_ + P.items_per_shard, P.n_items);
     const unsigned long long gmask_ = __ballot(1);
     const int lane_ = threadIdx.x & 63;
     const uint32_t grank_ = (uint32_t)__popcll(gmask_ & ((1ull << lane_) - 1ull));
     unsigned int pre_base_ = 0;
-    const bool pre_ok_ = CRT_GRAB_AHEAD && lo_ < P.n_items;
+    const bool pre_ok_ = lo_ < P.n_items;
     if (pre_ok_ && lane_ == __ffsll((long long)gmask_) - 1) pre_base_ = atomicAdd(P.item_next + home_ * ITEM_STRIDE, (unsigned int)__popcll(gmask_));
     if (stage != ST_NEW) {
         int deepest = (int)depth;
@@ -1477,9 +1448,6 @@ __device__ __forceinline__ void slab_pair_pruned(const float4 n0, const float4 n
 // of by comparisons: t_enter = max of the three near distances, t_exit = min of the three far ones (no operand is a NaN for a
 // ray with finite origin and 1/d and a finite box: x>y?x:y and v_max3 / v_min3 are the same numbers).  An empty slot is the
 // inverted box (+inf, -inf): t_enter = +inf, t_exit = -inf for either sign.
-#ifndef CRT_NODE_SIGNSEL
-#define CRT_NODE_SIGNSEL 1
-#endif
 template <bool PRUNE = true>
 __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
                                                  const F3 o, const F3 inv, const float bound, float& t0, float& t1, float& t2, float& t3)
@@ -1568,9 +1536,6 @@ __device__ __forceinline__ bool stack_pop(LDS& S, const MParams3& M3, const uint
 }
 // The same pop in two halves: the top LDS level is read when the step begins -- nothing a step pushes can land on it (pushes go to
 // levels >= sp) -- so that its latency hides behind the node / leaf gather instead of standing alone at the end of the step.
-#ifndef CRT_POP_AHEAD
-#define CRT_POP_AHEAD 1
-#endif
 template <class LDS>
 __device__ __forceinline__ int stack_top_ahead(LDS& S, const uint32_t id, const int sp, const int lv)
 {
@@ -1580,7 +1545,6 @@ __device__ __forceinline__ int stack_top_ahead(LDS& S, const uint32_t id, const 
 template <class LDS>
 __device__ __forceinline__ bool stack_pop_ahead(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, int& ref, const int top, const int lv)
 {
-#if CRT_POP_AHEAD
     if (sp == 0) return true;
     sp--;
     int en = top;
@@ -1589,10 +1553,6 @@ __device__ __forceinline__ bool stack_pop_ahead(LDS& S, const MParams3& M3, cons
     }
     ref = en;
     return false;
-#else
-    (void)top;
-    return stack_pop(S, M3, id, g, sp, ref, lv);
-#endif
 }
 template <class LDS>
 __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uint32_t id, const uint32_t g, int& sp, const int ref, const int lv)
@@ -1610,18 +1570,9 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
 // are the reference's (hit_AABB, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
 template <bool STATS, bool SORT = true, class LDS = Pool3Lds>
 __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
-                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const int dbg_loads, const int dbg_valu
-#ifdef CRT_STAMPS
-                                            , unsigned long long* dg_sec, unsigned long long& dg_t0
-#endif
+                                            const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp
                                             )
 {
-#ifdef CRT_STAMPS
-#define CRT_SEC4(i, dep) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(dep) : "memory"); unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_sec[i] += t_now - dg_t0; dg_t0 = t_now; }
-#else
-#define CRT_SEC4(i, dep)
-#endif
-#if CRT_NODE_SIGNSEL
     const char* nb = (const char*)sc.nodes4; // 32-bit byte offsets: scalar base + vector offset addressing
     const uint32_t noff = (uint32_t)ref * 128u;
     const uint32_t ox = noff + ((__float_as_uint(inv.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv.y) >> 27) & 16u),
@@ -1630,34 +1581,10 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 96);
-#else
-    const float4* nd = (const float4*)((const char*)sc.nodes4 + (uint32_t)ref * 128u); // 32-bit byte offset: scalar base + vector offset addressing
-    const float4 a0 = nd[0], a1 = nd[1], a2 = nd[2], b0 = nd[3], b1 = nd[4], b2 = nd[5], rf = nd[6];
-#endif
-#if CRT_POP_AHEAD
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
-#else
-    const int top = 0;
-#endif
-    CRT_SEC4(2, a0.x + a1.x + a2.x + b0.x + b1.x + b2.x + rf.x)
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
-#if CRT_NODE_SIGNSEL
     slab_quad_pruned<SORT>(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3); // (SORT == pruning mode: CRT_SORT4)
-#else
-    slab_pair_pruned(a0, a1, a2, o, inv, bound, t0, t1);
-    slab_pair_pruned(b0, b1, b2, o, inv, bound, t2, t3);
-#endif
-#ifdef CRT_STAMPS
-    { // sensitivity probes (tools/diag_sens.sh): result-neutral extra divergent 16 B loads / dependent VALU per inner step
-        float dbg_acc = 0.0f;
-        for (int x = 0; x < dbg_loads; x++) dbg_acc += sc.nodes4[(size_t)(ref ^ (x + 1)) * 8 + (x & 7)].x;
-        for (int x = 0; x < dbg_valu; x++) dbg_acc = dbg_acc * 1.0001f + inv.x;
-        if (dbg_acc == 1.2345e-30f) t0 = 0.0f;
-    }
-#else
-    (void)dbg_loads; (void)dbg_valu;
-#endif
     const float inf = pinf();
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
     // ascending by entry distance: (0,1)(2,3)(0,2)(1,3)(1,2)
@@ -1687,8 +1614,6 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     }
     sp = sp_new;
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-    CRT_SEC4(3, sp + r0)
-#undef CRT_SEC4
     if (c0) { ref = r0; return false; }
     return stack_pop_ahead(S, M, id, g, sp, ref, top, LV); // (no child was hit: nothing was pushed, the top is the one read above)
 }
@@ -1730,11 +1655,7 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 // CRT_TRAVERSAL_EXACT visits every child that is hit whatever the order (no bound shrinks): it only brings the nearest to the front
 // (three exchanges instead of five: what the any-hit rays gain from a full order is less than the two exchanges cost -- C2 -0.7 %,
 // veach-mis -0.6 %); -DCRT_EXACT_FULLSORT restores the full network
-#ifdef CRT_EXACT_FULLSORT
-#define CRT_SORT4(mode) true
-#else
 #define CRT_SORT4(mode) ((mode) != 2)
-#endif
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
 template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false>
@@ -1757,21 +1678,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     TravCounters tc;
     tc.inner = tc.leaf = tc.tests = tc.hits = 0;
     uint32_t max_sp = 0;
-#ifdef CRT_EXIT_HIST
-    const unsigned long long xh_t0 = wall_clock64();
-#endif
-#ifdef CRT_STAMPS
-    unsigned long long dg_cyc[PH3_N + 1] = {0, 0, 0, 0, 0, 0};
-    unsigned dg_iter[PH3_N] = {0, 0, 0, 0, 0}, dg_lanes[PH3_N] = {0, 0, 0, 0, 0};
-    unsigned long long dg_prev = __builtin_amdgcn_s_memtime();
-#define CRT_STAMP3(i) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_cyc[i] += t_now - dg_prev; dg_prev = t_now; }
-    // sections of the inner step: [0] ring id arrived, [1] record arrived, [2] node arrived, [3] boxes + push, [4] pop, [5] write-back + ring append
-    unsigned long long dg_sec[6] = {0, 0, 0, 0, 0, 0}, dg_t0 = 0;
-#define CRT_SEC3(i, dep) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(dep) : "memory"); unsigned long long t_now = __builtin_amdgcn_s_memtime(); dg_sec[i] += t_now - dg_t0; dg_t0 = t_now; }
-#else
-#define CRT_STAMP3(i)
-#define CRT_SEC3(i, dep)
-#endif
+    int n_exact = 0; // rays on the reference-arithmetic path (RF_EXACT) that are in the traversal phases of this pool
 
     // ring state: wave-uniform scalars
     int qn[PH3_N], qh[PH3_N], qt[PH3_N]; // entries, head, tail (head and tail in [0, POOL3_QCAP))
@@ -1820,7 +1727,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 // The logic phases read their parameters from the kernel-argument segment again, through a pointer the compiler cannot see
 // through: parameters that are only needed there (camera, tiling, work-item cursors, pool planes ...) would otherwise be
 // hoisted into scalar registers for the whole kernel and push the ring cursors of the traversal steps out into VGPR lanes.
-#ifndef CRT_NO_LOCAL_PARAMS
 #define LOGIC_PARAMS()                                                                                                     \
     const __attribute__((address_space(4))) char* ka_ = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr(); \
     asm volatile("" : "+s"(ka_));                                                                                          \
@@ -1833,9 +1739,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     const LParams& Pl = pu_.p;                                                                                             \
     Tables<false> tl;                                                                                                      \
     tl.mats = Pl.sc.mats; tl.lights = Pl.sc.lights;
-#else
-#define LOGIC_PARAMS() const LParams& Pl = P; const Tables<false>& tl = tb;
-#endif
 
     for (;;) {
       int act;
@@ -1856,103 +1759,67 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             act = best < 8 ? PH3_NONE : (best & 7); // (best < 8: every ray of the pool is dead)
         }
         if (act > PH3_LEAF) break;
-        CRT_STAMP3(PH3_N)
-#ifdef CRT_STAMPS
-        dg_iter[act]++;
-#endif
-        if (act == PH3_INNER) {
+        // Rays with non-finite operands (RF_EXACT: a handful per frame) walk the 2-wide reference topology with the reference's own
+        // box arithmetic and, in the 16-bit layout, keep their stack in the global area.  n_exact counts those in flight in this pool
+        // (a wave-uniform scalar): while it is zero -- practically always -- the steps run in the form that has none of that handling.
+        auto inner_arm = [&](auto may_exact_) __attribute__((always_inline)) {
+            constexpr bool MAY_EXACT = decltype(may_exact_)::value;
             // ---- inner-node step: the child boxes, nearest child next, the other hit children pushed ----
-#ifdef CRT_STAMPS
-            dg_t0 = __builtin_amdgcn_s_memtime();
-#endif
             POP3(PH3_INNER)
-#ifdef CRT_STAMPS
-            dg_lanes[PH3_INNER] += (unsigned)take;
-#endif
-            CRT_SEC3(0, id)
             bool t_done = false;
             int t_ref = 0;
             uint32_t t_flags = 0;
             if (on) {
-#if CRT_INV_LDS
-                const float4 qa = S.A[id], qc = S.C[id];
-                const uint32_t qd = S.D[id];
-                CRT_SEC3(1, qa.x + qc.x + __uint_as_float(qd))
-                int ref = __float_as_int(qc.w);
-                const F3 o = f3(qa.x, qa.y, qa.z), inv = f3(qc.x, qc.y, qc.z);
-#else
                 const float4 qa = S.A[id], qbd = S.B[id];
                 const uint32_t qd = S.D[id];
                 int ref = S.node[id];
-                CRT_SEC3(1, qa.x + qbd.x + __uint_as_float(qd))
                 const F3 o = f3(qa.x, qa.y, qa.z), inv = inv3_exact(f3(qbd.x, qbd.y, qbd.z));
-#endif
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
                 // (MODE 2 = CRT_TRAVERSAL_EXACT: the same traversal without this bound; +inf = no bound -- a box entered at +inf is still
                 // a box the reference enters, which matters to the reference-arithmetic step of the rays with non-finite operands)
-#if defined(CRT_VIS_NOPRUNE) /* measurement only: visibility rays unpruned */
-                const float bound = (MODE == 0 && (qd & RF_HASHIT) && !(qd & RF_ANYHIT)) ? prune_bound(qa.w, o, inv) : pinf();
-#else
                 const float bound = (MODE == 0 && (qd & (RF_ANYHIT | RF_HASHIT))) ? prune_bound(qa.w, o, inv) : pinf();
-#endif
                 bool done = false;
                 if (MODE == 1) {
                     const float4 qb = S.B[id];
                     done = inner2_step<1, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
+                } else if (!MAY_EXACT) {
+                    done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp);
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
-#ifdef CRT_STAMPS
-                    if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu, dg_sec, dg_t0);
-#else
-                    if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp, M3.dbg_loads, M3.dbg_valu);
-#endif
-                    if (__builtin_amdgcn_ballot_w64(ex)) { // a handful of rays per frame: reference arithmetic on the reference topology
+                    if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp);
+                    if (__builtin_amdgcn_ballot_w64(ex)) { // reference arithmetic on the reference topology
                         if (ex) {
                             const float4 qb = S.B[id];
                             done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                         }
                     }
                 }
-                CRT_SEC3(4, ref + sp)
-#if CRT_INV_LDS
-                S.C[id].w = __int_as_float(ref);
-#else
                 S.node[id] = ref;
-#endif
                 S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
                 if (STATS && done && (qd & RF_HASHIT)) tc.hits++; // (an any-hit ray that records a hit ends in the leaf step)
                 t_done = done; t_ref = ref; t_flags = qd;
             }
+            if (MAY_EXACT && MODE != 1) n_exact -= (int)__popcll(__ballot(on && t_done && (t_flags & RF_EXACT) != 0));
             PUSH_TRAV()
-            CRT_SEC3(5, nph)
-        } else {
+        };
+        auto leaf_arm = [&](auto may_exact_) __attribute__((always_inline)) {
+            constexpr bool MAY_EXACT = decltype(may_exact_)::value;
             // ---- leaf step: the record's two triangles in one packed computation ----
             POP3(PH3_LEAF)
-#ifdef CRT_STAMPS
-            dg_lanes[PH3_LEAF] += (unsigned)take;
-#endif
             bool t_done = false;
             int t_ref = 0;
             uint32_t t_flags = 0;
             if (on) {
                 const float4 qa = S.A[id], qb = S.B[id];
-#if CRT_INV_LDS
-                int ref = __float_as_int(S.C[id].w);
-#else
                 int ref = S.node[id];
-#endif
                 uint32_t qd = S.D[id];
                 const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
                 float T = qa.w;
                 int tri = __float_as_int(qb.w);
                 int sp = (int)(qd & 0xffu);
-                const int lv = lds_levels<LDS3>((qd & RF_EXACT) != 0);
-#if CRT_POP_AHEAD
+                const int lv = MAY_EXACT || MODE == 1 ? lds_levels<LDS3>((qd & RF_EXACT) != 0) : (int)LDS3::LV;
                 const int top = stack_top_ahead(S, id, sp, lv);
-#else
-                const int top = 0;
-#endif
                 const bool any_hit = (qd & RF_ANYHIT) != 0;
                 int best_leaf = tri - (int)((qd >> 8) & 0xffffu); // first triangle of the leaf that holds the best hit (-1 - 0 if none)
                 bool done = false;
@@ -1990,75 +1857,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 qd = (qd & 0xff000000u) | ((uint32_t)(tri - best_leaf) << 8 & 0xffff00u) | (uint32_t)sp;
                 if (!any_hit) S.A[id].w = T;
                 S.B[id].w = __int_as_float(tri);
-#if CRT_INV_LDS
-                S.C[id].w = __int_as_float(ref);
-#else
                 S.node[id] = ref;
-#endif
                 S.D[id] = qd;
                 if (STATS && done && tri >= 0) tc.hits++;
                 t_done = done; t_ref = ref; t_flags = qd;
             }
+            if (MAY_EXACT && MODE != 1) n_exact -= (int)__popcll(__ballot(on && t_done && (t_flags & RF_EXACT) != 0));
             PUSH_TRAV()
+        };
+        const bool plain = MODE == 1 || n_exact == 0;
+        if (act == PH3_INNER) {
+            if (plain)
+                inner_arm(std::false_type{});
+            else
+                inner_arm(std::true_type{});
+        } else {
+            if (plain)
+                leaf_arm(std::false_type{});
+            else
+                leaf_arm(std::true_type{});
         }
-        CRT_STAMP3(act)
       }
         if (act == PH3_NONE) break;
-        CRT_STAMP3(PH3_N)
-#ifdef CRT_STAMPS
-        dg_iter[act]++;
-#endif
         if (act == PH3_LA) {
             POP3(PH3_LA)
-#ifdef CRT_STAMPS
-            dg_lanes[PH3_LA] += (unsigned)take;
-#endif
+            bool new_exact = false;
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
                 nph = logic_A<MODE>(Pl, tl, g, S.A[id], S.B[id], nr, cnt, ALL);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
+            n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
         } else if (act == PH3_LB) {
             POP3(PH3_LB)
-#ifdef CRT_STAMPS
-            dg_lanes[PH3_LB] += (unsigned)take;
-#endif
+            bool new_exact = false;
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
                 nph = logic_B<MODE>(Pl, g, S.A[id], S.B[id], nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
+                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
+            n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
         } else {
             POP3(PH3_LC)
-#ifdef CRT_STAMPS
-            dg_lanes[PH3_LC] += (unsigned)take;
-#endif
+            bool new_exact = false;
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
                 if (QUERY ? query_C(Pl, g, S.A[id], S.B[id], nr) : logic_C(Pl, tl, g, cnt, nr))
-                    nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0);
+                    nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
+            n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
         }
-        CRT_STAMP3(act)
     }
 #undef PUSH3
 #undef PUSH_TRAV
 #undef POP3
 #undef LOGIC_PARAMS
 
-#ifdef CRT_EXIT_HIST
-    if (lane == 0) { // histogram of wave lifetimes in CRT_EXIT_HIST-microsecond buckets (wall_clock64: 100 MHz)
-        unsigned long long b_ = (wall_clock64() - xh_t0) / (100ull * CRT_EXIT_HIST);
-        if (b_ > 19) b_ = 19;
-        atomicAdd(&M.counters[(blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE + C_DIAG + b_], 1ull);
-    }
-#endif
     // ---- counters ----
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths), un = wave_sum(cnt.untraced);
     unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
@@ -2069,19 +1929,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         atomicAdd(&cs[C_PATHS], (unsigned long long)pa);
         atomicAdd(&cs[C_UNTRACED], (unsigned long long)un);
     }
-#ifdef CRT_STAMPS
-    if (lane == 0) {
-        atomicAdd(&cs[C_CYC_LOGIC], dg_cyc[PH3_LA] + dg_cyc[PH3_LB] + dg_cyc[PH3_LC]); atomicAdd(&cs[C_CYC_LEAF], dg_cyc[PH3_LEAF]);
-        atomicAdd(&cs[C_CYC_INNER], dg_cyc[PH3_INNER]); atomicAdd(&cs[C_CYC_OTHER], dg_cyc[PH3_N]);
-        for (int i = 0; i < PH3_N; i++) {
-            atomicAdd(&cs[C_DIAG + i], (unsigned long long)dg_iter[i]); atomicAdd(&cs[C_DIAG + PH3_N + i], (unsigned long long)dg_lanes[i]);
-            atomicAdd(&cs[C_DIAG + 2 * PH3_N + i], dg_cyc[i]);
-        }
-        for (int i = 0; i < 5; i++) atomicAdd(&cs[C_DIAG + 3 * PH3_N + i], dg_sec[i]); // [5] = the inner phase's total minus these
-    }
-    if (lane == 0 && false) {
-    }
-#endif
     if (STATS) {
         uint32_t a = wave_sum(tc.inner), b = wave_sum(tc.leaf), c = wave_sum(tc.tests), d = wave_sum(tc.hits);
         uint32_t ms = max_sp;
@@ -2861,9 +2708,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                     M3.M = M;
                     M3.spill = (int*)sc->spill[0].p; // (one word per entry; the buffer is sized for the two-word entries of k_trace)
                     M3.force_exact = (prm->flags & CRT_FLAG_FORCE_EXACT) ? 1u : 0u;
-                    M3.dbg_loads = (int32_t)env_u32("CRT_DBG_LOADS", 0) ; M3.dbg_valu = (int32_t)env_u32("CRT_DBG_VALU", 0);
-                    if (!std::getenv("CRT_DBG_LOADS")) M3.dbg_loads = 0;
-                    if (!std::getenv("CRT_DBG_VALU")) M3.dbg_valu = 0;
+                    M3.dbg_loads = 0; M3.dbg_valu = 0;
                     if (!bbprof_launch(kern3, M3, blocks, st)) hipLaunchKernelGGL(kern3, dim3(blocks), dim3(64), 0, st, M3);
                 }
                 HIP_CHECK(hipGetLastError());
@@ -3300,13 +3145,8 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                             todo.push_back(Todo{ch[i].ref, refs[i], cur.depth + 1});
                         } else refs[i] = ch[i].ref;
                     } else {
-#if CRT_NODE_SIGNSEL
                         // empty slot: the inverted box (t_enter = +inf, t_exit = -inf whatever the signs of the direction)
                         for (int a = 0; a < 3; a++) { lo[i][a] = std::numeric_limits<float>::infinity(); hi[i][a] = -std::numeric_limits<float>::infinity(); }
-#else
-                        // empty slot: a box of NaNs fails every comparison of the slab test
-                        for (int a = 0; a < 3; a++) { lo[i][a] = qn_; hi[i][a] = qn_; }
-#endif
                         refs[i] = ~0x7ffffff0; // (never followed)
                     }
                 }
@@ -3316,19 +3156,10 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                         coord_max = (m <= FLT_MAX && coord_max <= FLT_MAX) ? std::max(coord_max, m) : std::numeric_limits<float>::infinity();
                     }
                 float4* o = &nodes4[(size_t)cur.slot * 8];
-#if CRT_NODE_SIGNSEL
                 for (int a = 0; a < 3; a++) { // plane-major: [2a] = lo of axis a of the four children, [2a + 1] = hi
                     o[2 * a + 0] = make_float4(lo[0][a], lo[1][a], lo[2][a], lo[3][a]);
                     o[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]);
                 }
-#else
-                for (int pr = 0; pr < 2; pr++) { // children (0,1) then (2,3), pair-packed like nodes3
-                    const int i = 2 * pr, j = i + 1;
-                    o[pr * 3 + 0] = make_float4(lo[i][0], lo[j][0], lo[i][1], lo[j][1]);
-                    o[pr * 3 + 1] = make_float4(lo[i][2], lo[j][2], hi[i][0], hi[j][0]);
-                    o[pr * 3 + 2] = make_float4(hi[i][1], hi[j][1], hi[i][2], hi[j][2]);
-                }
-#endif
                 o[6] = make_float4(as_float(refs[0]), as_float(refs[1]), as_float(refs[2]), as_float(refs[3]));
                 o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }

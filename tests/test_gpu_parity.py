@@ -172,7 +172,7 @@ def test_fast_equals_reference_full_frame(renders, name):
 def test_seed_changes_image_and_is_reproducible(renders):
     eye, iv, fov = util.camera("cornell-box")
     r = renders["cornell-box"]
-    r.traversal = crt.TRAVERSAL_FAST
+    r.traversal = crt.TRAVERSAL_EXACT
     r.set_spp(2)
     a = r.run_view(eye, iv, fov, width=160, height=120).copy()
     b = r.run_view(eye, iv, fov, width=160, height=120).copy()
@@ -192,7 +192,7 @@ def test_sharded_render_reassembles(renders):
     from cudaraytracing_amd.distributed import untile_numpy
     eye, iv, fov = util.camera("veach-mis")
     r = renders["veach-mis"]
-    r.traversal = crt.TRAVERSAL_FAST
+    r.traversal = crt.TRAVERSAL_EXACT
     r.set_spp(2)
     w, h = 200, 150
     full = r.run_view(eye, iv, fov, width=w, height=h).copy()
@@ -250,7 +250,7 @@ def test_bench_with_two_ranks_on_one_device(renders, tmp_path):
     eye, iv, fov = util.camera(name)
     one = renders[name]
     one.set_spp(4)
-    one.traversal = crt.TRAVERSAL_FAST
+    one.traversal = crt.TRAVERSAL_EXACT
     rgb = one.run_view(eye, iv, fov, width=200, height=152)
     assert line["rays_per_frame"] == one.stats["rays"]
     assert np.array_equal(np.asarray(Image.open(png)), rgb)
@@ -504,7 +504,7 @@ def test_all_pipeline_variants_agree(renders, pipeline, monkeypatch):
         t = util.task(name)
         eye, iv, fov = util.camera(name)
         r = renders[name]
-        r.traversal = crt.TRAVERSAL_FAST
+        r.traversal = crt.TRAVERSAL_EXACT
         r.set_spp(2)
         rgb = r.run_view(eye, iv, fov, width=128, height=96)
         orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 128, 96, 2, t.P_RR, t.light_sample_n)
@@ -520,7 +520,7 @@ def test_progressive_ranges_equal_one_shot(renders, pipeline, monkeypatch):
     name = "veach-mis"
     eye, iv, fov = util.camera(name)
     r = renders[name]
-    r.traversal = crt.TRAVERSAL_FAST
+    r.traversal = crt.TRAVERSAL_EXACT
     r.set_spp(7)
     ref = r.run_view(eye, iv, fov, width=96, height=72).copy()
     ref_mean, ref_rays = r.mean_buffer.copy(), r.stats["rays"]
@@ -544,7 +544,7 @@ def test_previews_of_a_progressive_render(renders, pipeline, monkeypatch):
     name = "cornell-box"
     eye, iv, fov = util.camera(name)
     r = renders[name]
-    r.traversal = crt.TRAVERSAL_FAST
+    r.traversal = crt.TRAVERSAL_EXACT
     w, h, spp = 96, 72, 12
     r.set_spp(spp)
     ref = r.run_view(eye, iv, fov, width=w, height=h).copy()
@@ -581,7 +581,7 @@ def test_samples_rendered_in_chunks_equal_one_launch(renders, pipeline, monkeypa
     eye, iv, fov = util.camera(name)
     r = renders[name]
     r.set_spp(7)
-    r.traversal = crt.TRAVERSAL_FAST
+    r.traversal = crt.TRAVERSAL_EXACT
     one = r.run_view(eye, iv, fov, width=64, height=48).copy()
     mean_one = r.mean_buffer.copy()
     launches_one = r.stats["kernel_launches"]
@@ -594,48 +594,52 @@ def test_samples_rendered_in_chunks_equal_one_launch(renders, pipeline, monkeypa
 
 
 def test_zero_contribution_samples_are_answered_without_traversal(renders):
-    """FAST answers next-event samples whose contribution is exactly zero without tracing them (adding +0 cannot change L_dir):
-    same frame, same reference ray counts, with and without CRT_FLAG_TRACE_ALL; REFERENCE traces everything."""
+    """The default mode (CRT_TRAVERSAL_EXACT) and FAST answer next-event samples whose contribution is exactly zero without tracing
+    them (adding +0 cannot change L_dir): same frame, same reference ray counts, with and without CRT_FLAG_TRACE_ALL; REFERENCE
+    traces everything."""
     for name in ("cornell-box", "veach-mis"):
         t = util.task(name)
         eye, iv, fov = util.camera(name)
         r = renders[name]
         r.set_spp(3)
         out = {}
-        for key, trav, flags in (("fast", crt.TRAVERSAL_FAST, 0), ("all", crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL),
-                                 ("ref", crt.TRAVERSAL_REFERENCE, 0)):
+        for key, trav, flags in (("exact", crt.TRAVERSAL_EXACT, 0), ("exact_all", crt.TRAVERSAL_EXACT, crt.FLAG_TRACE_ALL), ("fast", crt.TRAVERSAL_FAST, 0),
+                                 ("fast_all", crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), ("ref", crt.TRAVERSAL_REFERENCE, 0)):
             r.traversal, r.extra_flags = trav, flags
             rgb = r.run_view(eye, iv, fov, width=160, height=120)
             out[key] = (rgb.copy(), r.mean_buffer.copy(), dict(r.stats))
-        r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
-        for key in ("all", "ref"):
-            assert np.array_equal(out[key][0], out["fast"][0]) and np.array_equal(util.bits(out[key][1]), util.bits(out["fast"][1]))
-            assert out[key][2]["rays"] == out["fast"][2]["rays"] and out[key][2]["shadow_rays"] == out["fast"][2]["shadow_rays"]
-            assert out[key][2]["rays_untraced"] == 0
-        un = out["fast"][2]["rays_untraced"]
-        assert 0 < un < out["fast"][2]["shadow_rays"]
+        r.traversal, r.extra_flags = crt.TRAVERSAL_EXACT, 0
+        for key in ("exact_all", "fast", "fast_all", "ref"):
+            assert np.array_equal(out[key][0], out["exact"][0]) and np.array_equal(util.bits(out[key][1]), util.bits(out["exact"][1])), key
+            assert out[key][2]["rays"] == out["exact"][2]["rays"] and out[key][2]["shadow_rays"] == out["exact"][2]["shadow_rays"], key
+        for key in ("exact_all", "fast_all", "ref"):
+            assert out[key][2]["rays_untraced"] == 0, key
+        un = out["exact"][2]["rays_untraced"]
+        assert 0 < un < out["exact"][2]["shadow_rays"] and un == out["fast"][2]["rays_untraced"]
         orgb, omean, _, st = util.oracle_scene(name).render(eye, iv, fov, 160, 120, 3, t.P_RR, t.light_sample_n)
-        assert np.array_equal(util.bits(out["fast"][1]), util.bits(omean)) and out["fast"][2]["rays"] == st["rays"]
+        assert np.array_equal(util.bits(out["exact"][1]), util.bits(omean)) and out["exact"][2]["rays"] == st["rays"]
 
 
 def test_baseline_size_frame_properties(renders):
-    """BASELINE configuration C2 at full size (cornell-box 800x600 spp 512, 1.1 G rays): the default path, the path with every
-    sample traced, the exhaustive REFERENCE traversal and a render split into progressive ranges give the same frame bit for
-    bit and the same ray counts."""
+    """BASELINE configuration C2 at full size (cornell-box 800x600 spp 512, 1.1 G rays) in the DEFAULT mode (CRT_TRAVERSAL_EXACT, the
+    mode the benchmark number is quoted in): the same mode with every sample traced, FAST with and without that, the exhaustive
+    REFERENCE traversal and a render split into progressive ranges give the same frame -- float bits of the mean buffer -- and the
+    same ray counts."""
     name = "cornell-box"
     eye, iv, fov = util.camera(name)
     r = renders[name]
     r.set_spp(512)
-    r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
+    r.traversal, r.extra_flags = crt.TRAVERSAL_EXACT, 0
     rgb = r.run_view(eye, iv, fov).copy()
     mean, st = r.mean_buffer.copy(), dict(r.stats)
     assert st["paths"] == 800 * 600 * 512 and st["rays"] > 10 ** 9 and 0 < st["rays_untraced"] < st["shadow_rays"]
-    for trav, flags in ((crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0)):
+    for trav, flags in ((crt.TRAVERSAL_EXACT, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_FAST, 0), (crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0)):
         r.traversal, r.extra_flags = trav, flags
         rgb2 = r.run_view(eye, iv, fov)
-        assert np.array_equal(rgb2, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean))
-        assert r.stats["rays"] == st["rays"] and r.stats["shadow_rays"] == st["shadow_rays"] and r.stats["rays_untraced"] == 0
-    r.traversal, r.extra_flags = crt.TRAVERSAL_FAST, 0
+        assert np.array_equal(rgb2, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean)), (trav, flags)
+        assert r.stats["rays"] == st["rays"] and r.stats["shadow_rays"] == st["shadow_rays"], (trav, flags)
+        assert r.stats["rays_untraced"] == (st["rays_untraced"] if (trav, flags) == (crt.TRAVERSAL_FAST, 0) else 0), (trav, flags)
+    r.traversal, r.extra_flags = crt.TRAVERSAL_EXACT, 0
     out = None
     for b, c in ((0, 100), (100, 156), (256, 256)):
         out = r.run_view_range(eye, iv, fov, b, c)

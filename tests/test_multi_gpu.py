@@ -41,7 +41,7 @@ def test_ranks_on_one_device_reproduce_the_single_device_frame(single, name, w, 
     eye, iv, fov = util.camera(name)
     one = single[name]
     one.set_spp(4)
-    one.traversal = crt.TRAVERSAL_FAST
+    one.traversal = crt.TRAVERSAL_EXACT
     rgb = one.run_view(eye, iv, fov, width=w, height=h).copy()
     mean = one.mean_buffer.copy()
     m = _multi(name, [0] * ranks, crt.GATHER_COPY, 4)
@@ -73,7 +73,7 @@ def test_rccl_all_gather_runs_on_a_one_rank_communicator(single):
     eye, iv, fov = util.camera(name)
     one = single[name]
     one.set_spp(2)
-    one.traversal = crt.TRAVERSAL_FAST
+    one.traversal = crt.TRAVERSAL_EXACT
     rgb = one.run_view(eye, iv, fov, width=160, height=120).copy()
     m = _multi(name, [0], crt.GATHER_RCCL, 2)
     try:
@@ -132,7 +132,7 @@ def test_bench_started_plainly_starts_its_own_ranks(single, tmp_path):
     eye, iv, fov = util.camera("cornell-box")
     one = single["cornell-box"]
     one.set_spp(4)
-    one.traversal = crt.TRAVERSAL_FAST
+    one.traversal = crt.TRAVERSAL_EXACT
     rgb = one.run_view(eye, iv, fov, width=200, height=152)
     assert line["rays_per_frame"] == one.stats["rays"]
     assert np.array_equal(np.asarray(Image.open(png)), rgb)
@@ -147,7 +147,7 @@ def test_bench_multi_engine_one_process(single):
     eye, iv, fov = util.camera("cornell-box")
     one = single["cornell-box"]
     one.set_spp(4)
-    one.traversal = crt.TRAVERSAL_FAST
+    one.traversal = crt.TRAVERSAL_EXACT
     one.run_view(eye, iv, fov, width=200, height=152)
     assert line["rays_per_frame"] == one.stats["rays"]
 

@@ -78,13 +78,12 @@ def test_c4_full_size_on_one_device_in_two_launches():
         assert np.array_equal(rgb_all, rgb)
         assert np.array_equal(util.bits(one.mean_buffer), util.bits(mean))
         one.extra_flags = 0
-        # ... and the exhaustive REFERENCE traversal of the same 7.9 G rays (the pruning rule of FAST is not a theorem: the full-size
-        # C3 frame once found a ray it lost, csrc/crt_trace.h)
-        # ... and of CRT_TRAVERSAL_EXACT, the fast traversal without the pruning rule (provably REFERENCE's frame)
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_EXACT):
+        # ... and the exhaustive REFERENCE traversal of the same 7.9 G rays, and CRT_TRAVERSAL_FAST (the default mode plus distance pruning,
+        # whose rule is not a theorem: the full-size C3 frame once found a ray it lost, csrc/crt_trace.h)
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
             one.traversal = mode
             rgb_ref = one.run_view(eye, iv, fov, width=w, height=h)
-            one.traversal = crt.TRAVERSAL_FAST
+            one.traversal = crt.TRAVERSAL_EXACT
             assert one.stats["rays"] == st["rays"]
             diff = np.argwhere(np.any(util.bits(one.mean_buffer) != util.bits(mean), axis=2))
             assert diff.size == 0 and np.array_equal(rgb_ref, rgb), (mode, diff[:8])
@@ -139,10 +138,10 @@ def test_c5_shares_of_rank_0_and_rank_7_at_full_size():
         b0a, m0a, s0a = share(0, capi.FLAG_TRACE_ALL)
         assert s0a["rays"] == s0["rays"] and s0a["rays_untraced"] == 0 and s0["rays_untraced"] > 0
         assert np.array_equal(b0a, b0) and np.array_equal(util.bits(m0a), util.bits(m0))
-        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_EXACT):   # the exhaustive / the unpruned traversal of the same 7.6 G rays
+        for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):   # the exhaustive / the pruned traversal of the same 7.6 G rays
             one.traversal = mode
             b0r, m0r, s0r = share(0)
-            one.traversal = crt.TRAVERSAL_FAST
+            one.traversal = crt.TRAVERSAL_EXACT
             diff = np.argwhere(np.any(util.bits(m0r) != util.bits(m0), axis=1))
             assert s0r["rays"] == s0["rays"] and diff.size == 0 and np.array_equal(b0r, b0), (mode, diff[:8])
         b7, m7, s7 = share(7)
@@ -160,7 +159,7 @@ def test_c5_shares_of_rank_0_and_rank_7_at_full_size():
 
 def test_c3_full_size():
     """BASELINE configuration C3 at full size (veach-mis 800x600 spp 1024, 3.5 G rays, 42 % of them answered without traversal):
-    the default path, the path with every sample traced and the exhaustive REFERENCE traversal give the same frame bit for bit
+    the default mode (CRT_TRAVERSAL_EXACT), the same with every sample traced, FAST and the exhaustive REFERENCE traversal give the same frame bit for bit
     and the same ray counts; three 16x12 crops (a plate, a light, the last tile rows) equal the oracle at spp 1024."""
     name, w, h, spp = "veach-mis", 800, 600, 1024
     t = util.task(name)
@@ -170,11 +169,11 @@ def test_c3_full_size():
         rgb = r.run_view(eye, iv, fov, width=w, height=h).copy()
         mean, st = r.mean_buffer.copy(), dict(r.stats)
         assert st["paths"] == w * h * spp and st["rays"] > 3 * 10 ** 9 and st["rays_untraced"] > 0.3 * st["rays"]
-        for trav, flags in ((crt.TRAVERSAL_FAST, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_REFERENCE, 0), (crt.TRAVERSAL_EXACT, 0)):
+        for trav, flags in ((crt.TRAVERSAL_EXACT, crt.FLAG_TRACE_ALL), (crt.TRAVERSAL_FAST, 0), (crt.TRAVERSAL_REFERENCE, 0)):
             r.traversal, r.extra_flags = trav, flags
             rgb2 = r.run_view(eye, iv, fov, width=w, height=h)
             assert np.array_equal(rgb2, rgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(mean)), (trav, flags)
-            assert r.stats["rays"] == st["rays"] and r.stats["rays_untraced"] == (st["rays_untraced"] if trav == crt.TRAVERSAL_EXACT else 0)
+            assert r.stats["rays"] == st["rays"] and r.stats["rays_untraced"] == (st["rays_untraced"] if (trav, flags) == (crt.TRAVERSAL_FAST, 0) else 0)
         for crop in ((392, 300, 16, 12), (200, 140, 16, 12), (w - 16, h - 12, 16, 12)):
             x0, y0, cw, ch = crop
             orgb, omean, _, _ = _oracle_crop(name, w, h, spp, crop)

@@ -25,7 +25,7 @@ def phase_ranges():
     """Line ranges of the phase arms of k_mega3's main loop, found by their markers in the source."""
     lines = open(os.path.join(SRC, "crt_kernels.hip")).read().split("\n")
     k0 = next(i for i, l in enumerate(lines) if "void k_mega3(const MParams3 M3)" in l) + 1
-    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"if \(act == PH3_INNER\) \{"), ("leaf", r"leaf step: the record.s two triangles"),
+    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"auto inner_arm = "), ("leaf", r"auto leaf_arm = "), ("sched2", r"^\s*if \(act == PH3_INNER\) \{"),
              ("LA", r"if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"^\s*\} else \{\s*$"), ("end", r"^#undef PUSH3")]
     at, cur = [], k0
     for name, pat in marks:
@@ -35,9 +35,17 @@ def phase_ranges():
         cur += 1
     rng = [("prologue", k0, at[0][1] - 1)]
     for (n, a), (_, b) in zip(at[:-1], at[1:]):
-        rng.append((n, a, b - 1))
+        rng.append(("sched" if n == "sched2" else n, a, b - 1))
     rng.append(("epilogue", at[-1][1], at[-1][1] + 60))
-    return rng
+    # the traversal steps are lambdas instantiated twice (with / without rays on the reference-arithmetic path): the outermost frame
+    # of their code is the line of the call
+    calls = []
+    for i, l in enumerate(lines):
+        for name, pat in (("inner", "inner_arm(std::false_type{})"), ("inner_ex", "inner_arm(std::true_type{})"), ("leaf", "leaf_arm(std::false_type{})"),
+                          ("leaf_ex", "leaf_arm(std::true_type{})")):
+            if pat in l:
+                calls.append((name, i + 1, i + 1))
+    return calls + rng
 
 
 def function_map():

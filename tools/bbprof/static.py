@@ -62,7 +62,7 @@ def main():
         per_depth[depth][kind] += 1
     kinds = ["valu", "copy", "lane", "salu", "vmem", "flat", "lds", "ctl"]
     print("%-9s " % "phase" + " ".join("%6s" % k for k in kinds))
-    for ph in ["sched", "inner", "leaf", "LA", "LB", "LC", "other", "prologue", "epilogue"]:
+    for ph in ["sched", "inner", "leaf", "inner_ex", "leaf_ex", "LA", "LB", "LC", "other", "prologue", "epilogue"]:
         print("%-9s " % ph + " ".join("%6d" % per[ph][k] for k in kinds))
     print("by loop depth:")
     for d in sorted(per_depth):
