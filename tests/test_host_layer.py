@@ -210,3 +210,38 @@ def test_header_constants_match_the_python_mirror():
     import inspect
     src = inspect.getsource(crt.Render.__init__)
     assert "TRAVERSAL_EXACT" in src and "TRAVERSAL_FAST" not in src
+
+
+def test_the_documented_reference_side_binding_compiles(tmp_path):
+    """INTEGRATION.md section 2 shows the `Render` class a maintainer of the reference would drop in (talking to libcrt.so through
+    include/crt.h).  The code block is extracted and type-checked here -- against include/crt.h, the reference's vendored Eigen and
+    test-only declarations of the Scene / BVH / Triangle / Material / Object getters it calls (tests/shim_decls/Scene.h) -- with the
+    calls src/main.cu makes (main.cu:282, 368-377), so that a change of a struct in crt.h cannot silently break the documented binding."""
+    import shutil
+    import subprocess
+    eigen = "/root/reference/include"
+    if not os.path.isdir(os.path.join(eigen, "Eigen")) or not shutil.which("g++"):
+        pytest.skip("needs the reference's vendored Eigen (/root/reference) and g++")
+    text = open(os.path.join(util.ROOT, "INTEGRATION.md")).read()
+    sect = text[text.index("## 2. Reference-side shim"):]
+    code = sect[sect.index("```cpp") + 6:]
+    code = code[:code.index("```")]
+    assert "class Render" in code and "crt_scene_create" in code and "crt_render" in code
+    (tmp_path / "RenderCrt.h").write_text(code)
+    (tmp_path / "main.cpp").write_text('''
+#include "RenderCrt.h"
+int use(Scene* scene, Eigen::Vector3f eye, Eigen::Matrix3f inv_view, float fov_y)
+{
+    Render render(scene, 16, 0.8f, 1);                 // src/main.cu:282
+    render.set_spp(64); render.set_P_RR(0.6f); render.set_light_sample_n(2);
+    render.run_view(eye, inv_view, fov_y, nullptr);    // src/main.cu:372
+    unsigned char* fb = render.get_frame_buffer();
+    render.save_frame_buffer("out.png");
+    render.free();
+    return fb ? 0 : 1;
+}
+''')
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror=narrowing", "-I", os.path.join(util.ROOT, "include"),
+           "-I", os.path.join(util.ROOT, "tests", "shim_decls"), "-I", eigen, str(tmp_path / "main.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
