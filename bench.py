@@ -59,6 +59,8 @@ L2_PEAK_GBPS = 34500.0       # 8 XCDs x 16 channels x 128 B/clk at 2.1 GHz
 N_SIMDS = 1024               # 256 CUs x 4
 CLOCK_GHZ = 2.4
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")
+CENSUS_FILE = os.path.join(ROOT, "profiles", "bbprof_latest.json")
+GUIDE_VALU_CYCLES = 2.0      # MI355X_MICROARCH.md: a wave64 fp32 instruction issues in 2 cycles (the peak of the guide's convention)
 
 
 def parse_args():
@@ -146,10 +148,26 @@ def load_pmc(workload_key):
     return w, None
 
 
-def bounds_from_pmc(pmc, k_s):
-    """The three candidate bounds for one launch of duration k_s seconds; every fraction is <= 1 by construction."""
+def load_census(workload_key):
+    """The instruction census of `workload_key` (tools/bbprof/census.py) if it was taken on the code that is running."""
+    from cudaraytracing_amd import build as B
+    try:
+        d = json.load(open(CENSUS_FILE))
+    except Exception:
+        return None
+    if d.get("src_hash") != B.source_hash():
+        return None
+    return d.get("workloads", {}).get(workload_key)
+
+
+def bounds_from_pmc(pmc, k_s, census=None):
+    """The three candidate bounds for one launch of duration k_s seconds; every fraction is <= 1 by construction.
+    census (tools/bbprof): exact dynamic opcode counts priced with measured per-opcode issue costs -- the cycles per vector
+    instruction of THIS kernel's mix; without it the round-2 estimate from the coarse SQ_INSTS_VALU_* classes is used."""
     out = {}
     cyc = float(pmc.get("valu_cycles_per_instr", 3.35))
+    if census:
+        cyc = float(census["cycles_per_valu"])
     if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
         traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
         out["hbm"] = {"achieved": round(traffic / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -159,9 +177,17 @@ def bounds_from_pmc(pmc, k_s):
         ach = pmc["SQ_INSTS_VALU"] / k_s / 1e9
         out["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
                              "cycles_per_instr": cyc, "lane_utilization": pmc.get("valu_lane_utilization")}
-        rng = pmc.get("valu_cycles_per_instr_range")
-        if rng:  # all unclassified instructions at the cheapest / the dearest measured issue cost
+        rng = census["cycles_per_valu_range"] if census else pmc.get("valu_cycles_per_instr_range")
+        if rng:  # the unpriced instructions at the cheapest / the dearest measured issue cost
             out["valu_issue"]["frac_range"] = [round(ach * rng[0] / (N_SIMDS * CLOCK_GHZ), 4), round(ach * rng[1] / (N_SIMDS * CLOCK_GHZ), 4)]
+        out["valu_issue"]["frac_at_guide_peak"] = round(ach * GUIDE_VALU_CYCLES / (N_SIMDS * CLOCK_GHZ), 4)  # 2 cycles per instruction
+        out["valu_issue"]["cycles_per_instr_source"] = ("census: exact dynamic opcode counts (tools/bbprof) x measured per-opcode issue costs "
+                                                        "(tools/valu_issue_gen.py), %.2f %% of the instructions unpriced" % (100.0 * census["unpriced_share"])
+                                                        if census else "round-2 estimate from the SQ_INSTS_VALU_* classes")
+        if census:
+            out["valu_issue"]["census"] = {"valu_instructions_per_launch": census["valu_instructions_per_launch"], "lane_utilisation": round(census["lane_utilisation"], 4),
+                                           "tiers": {k: round(v, 4) for k, v in census["tiers"].items()},
+                                           "pmc_over_census_instructions": round(pmc["SQ_INSTS_VALU"] / census["valu_instructions_per_launch"], 4)}
     if pmc.get("TCC_REQ_sum") is not None or (pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None):
         req = pmc.get("TCC_REQ_sum")
         if req is None:
@@ -307,9 +333,17 @@ def main_rank(args):
     red_dev = torch.device("cpu") if one_device else device
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     r = torch.tensor([float(rays_local)], dtype=torch.float64, device=red_dev)
+    # per-rank view of a step (for reading a scaling curve): this rank's mean kernel time per frame, gathered from all ranks
+    k_local = float(np.mean([k for k in kernel_ms if k is not None])) if any(k is not None for k in kernel_ms) else 0.0
+    k_all = torch.zeros(max(1, world), dtype=torch.float64, device=red_dev)
+    k_all[rank if world > 1 else 0] = k_local
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(k_all, op=dist.ReduceOp.SUM)
+    rank_kernel_ms = [float(v) for v in k_all.tolist()]
+    if multi and mr is not None and mr.rank_stats:
+        rank_kernel_ms = [float(s_["kernel_ms"]) for s_ in mr.rank_stats]
     elapsed = float(t.item())
     rays_frame = float(r.item())
     ms_per_step = elapsed * 1e3 / args.steps
@@ -364,7 +398,7 @@ def main_rank(args):
                     "visited_bytes_per_ray": round(b_ray_visited, 1), "visited_achieved": round(contract_visited, 2)}
         pmc, pmc_note = (load_pmc("c2") if (c2 and single) else (None, "PMC passes exist for the C2 workload on one GPU only"))
         if pmc is not None:
-            bounds = bounds_from_pmc(pmc, k_ms * 1e-3)
+            bounds = bounds_from_pmc(pmc, k_ms * 1e-3, load_census("c2"))
             roofline["bounds"] = bounds
             if bounds:
                 name = max(bounds, key=lambda b: bounds[b]["frac"])
@@ -466,11 +500,11 @@ def main_rank(args):
                   "mrays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
                   "mrays_traced_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),
                   "untraced_frac": round(st3["rays_untraced"] / st3["rays"], 4),
-                  "all_rays_traced_ms": round(dt3a * 1e3, 3),
+                  "all_rays_traced_ms": round(dt3a * 1e3, 3), "value_all_rays_traced": round(st3a["rays"] / dt3a / 1e6, 2),
                   ("fast_mode_ms" if other3 == crt.TRAVERSAL_FAST else "exact_mode_ms"): round(dt3e * 1e3, 3)}
             p3, _ = load_pmc("c3")
             if p3 is not None:
-                c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3)
+                c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3, load_census("c3"))
             r3.free()
 
         # ---- CPU baseline + same-run parity gate: the oracle renders the 800x600 spp=--cpu-spp frame on one host
@@ -543,12 +577,31 @@ def main_rank(args):
             "rays_untraced_per_frame_rank0": int(untraced_local),
             "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
             "all_rays_traced": all_traced,
+            # the same numbers with EVERY ray of the reference traced (no zero-contribution samples answered without traversal):
+            # the figures to compare with tracers that count only rays they trace
+            "value_all_rays_traced": all_traced["mrays_per_sec"] if all_traced else None,
+            "ms_all_rays_traced": all_traced["ms_per_step"] if all_traced else None,
             **({other_name: other_mode} if other_name else {}),
             "mpaths_per_sec": round(args.width * args.height * args.spp * args.steps / elapsed / 1e6, 2),
             "roofline": roofline,
             "exact_vs_reference": exact_vs_reference,
             "fast_vs_reference": fast_vs_reference,
         }
+        if n_gpus > 1:
+            # what a rank's step is made of: its kernel (min / max over the ranks: the interleaved tiles balance the load, the spread
+            # says how well), and what is not kernel time -- the all-gather, the de-interleave, the work-item order pass, the accumulate
+            # kernel and launch gaps.  predicted_share_ms: the one-GPU model of DESIGN.md 8 (every launch ends with its waves running
+            # their pools dry: a fixed tail, the rest divides by N).
+            line["per_rank"] = {"kernel_ms_min": round(min(rank_kernel_ms), 3), "kernel_ms_max": round(max(rank_kernel_ms), 3),
+                                "kernel_ms_mean": round(float(np.mean(rank_kernel_ms)), 3), "kernel_ms": [round(v, 3) for v in rank_kernel_ms],
+                                "non_kernel_ms_per_step": round(ms_per_step - max(rank_kernel_ms), 3)}
+            try:
+                sm = json.load(open(os.path.join(ROOT, "profiles", "share_model.json")))
+                if c2 and sm.get("workload") == "c2":
+                    line["per_rank"]["predicted_share_ms"] = round(sm["tail_ms"] + (sm["one_gpu_kernel_ms"] - sm["tail_ms"]) / n_gpus, 3)
+                    line["per_rank"]["predicted_share_model"] = sm.get("note")
+            except Exception:
+                pass
         if multi:
             line["multi_info"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in mr.info.items()}
         if parity is not None:
