@@ -135,6 +135,21 @@ __device__ __forceinline__ bool slot_to_pixel(uint32_t slot, uint32_t rank, uint
     return i < width && j < height;
 }
 
+// Loads / stores that say "global memory" in their type.  The logic phases of k_mega3 take their pointers out of a copy of the kernel
+// arguments (LOGIC_PARAMS), where the compiler no longer sees that they are kernel arguments: plain accesses through them are FLAT
+// instructions, which count on the LDS / scalar-memory counter too -- every s_waitcnt for an s_load then waits for the path-state
+// loads in flight.
+#define CRT_GAS __attribute__((address_space(1)))
+typedef float crt_f4v_ __attribute__((ext_vector_type(4)));
+typedef uint32_t crt_u4v_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gld(const float4* p) { const crt_f4v_ v = *(const CRT_GAS crt_f4v_*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 gld(const uint4* p) { const crt_u4v_ v = *(const CRT_GAS crt_u4v_*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ int32_t gld(const int32_t* p) { return *(const CRT_GAS int32_t*)p; }
+__device__ __forceinline__ uint32_t gld(const uint32_t* p) { return *(const CRT_GAS uint32_t*)p; }
+__device__ __forceinline__ void gst(float4* p, const float4 v) { crt_f4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(CRT_GAS crt_f4v_*)p = t; }
+__device__ __forceinline__ void gst(uint4* p, const uint4 v) { crt_u4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(CRT_GAS crt_u4v_*)p = t; }
+__device__ __forceinline__ void gst(float* p, const float v) { *(CRT_GAS float*)p = v; }
+
 // Takes the next work item for every lane that is active here with ONE atomic per wave and
 // shard (ballot of the active lanes, the first one adds their count, prefix rank per lane).
 __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, unsigned int* item_next, uint32_t per, uint32_t n_items,
@@ -149,12 +164,12 @@ __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, un
         const uint32_t hi = min(lo + per, n_items);
         unsigned int* cur = item_next + sh * ITEM_STRIDE;
         // cursors only grow, so a stale read can at worst cost one fruitless atomic
-        if (lo + __hip_atomic_load(cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi) continue;
+        if (lo + __hip_atomic_load((CRT_GAS unsigned int*)cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= hi) continue;
         const unsigned long long mask = __ballot(1);
         const int leader = __ffsll((long long)mask) - 1;
         const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
         unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(cur, (unsigned int)__popcll(mask));
+        if (lane == leader) base = __hip_atomic_fetch_add((CRT_GAS unsigned int*)cur, (unsigned int)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base); // leader is the first active lane
         const unsigned long long idx = (unsigned long long)lo + base + rank;
         if (idx < hi) { item = (uint32_t)idx; break; }
@@ -193,7 +208,7 @@ template <bool LDS_TABLES> struct Tables {
     const uint4* lights;
 };
 template <bool LDS_TABLES>
-__device__ __forceinline__ float4 mat_row(const Tables<LDS_TABLES>& tb, uint32_t mat, int row) { return tb.mats[mat * 3 + row]; }
+__device__ __forceinline__ float4 mat_row(const Tables<LDS_TABLES>& tb, uint32_t mat, int row) { return gld(&tb.mats[mat * 3 + row]); }
 
 // Sets up next-event sample q of the current vertex: Render.cuh:262-272 (+ :274-283 evaluated
 // ahead of the visibility test; the value is only added if the shadow ray is not blocked).
@@ -204,7 +219,7 @@ __device__ __forceinline__ void setup_shadow_lg(const LParams& P, Lane& s, F3 f_
     U4 rl = rng_draw(P.seed, s.pixel_index, s.k, s.depth, RNG_NEE, s.q);
     const uint32_t ti = rl.x - fast_div(rl.x, lg.z, lg.w) * lg.y; // rand % triangle count (DeviceLights.cuh:35)
     const float4* lt = sc.ltri + (size_t)(lg.x + ti) * 4;
-    float4 l0 = lt[0], l1 = lt[1], l2 = lt[2], l3 = lt[3];
+    float4 l0 = gld(lt), l1 = gld(lt + 1), l2 = gld(lt + 2), l3 = gld(lt + 3);
     float alpha = rng_uniform(rl.y); // DeviceTriangle.cuh:69-71
     float beta = rng_uniform(rl.z) * (1 - alpha);
     float gamma = 1 - alpha - beta;
@@ -235,7 +250,7 @@ __device__ __forceinline__ void setup_shadow_lg(const LParams& P, Lane& s, F3 f_
 template <bool LDS_TABLES>
 __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_TABLES>& tb, Lane& s, F3 f_r)
 {
-    setup_shadow_lg(P, s, f_r, tb.lights[fast_div(s.q, P.lsn_div.m, P.lsn_div.sh)]);
+    setup_shadow_lg(P, s, f_r, gld(&tb.lights[fast_div(s.q, P.lsn_div.m, P.lsn_div.sh)]));
 }
 
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
@@ -249,7 +264,7 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
     if (emissive) {
         L = deepest == 0 ? add3(f3(0.0f, 0.0f, 0.0f), ke) : f3(0.0f, 0.0f, 0.0f); // :249-255, :323
     } else {
-        float4 a = pl.rec_a[(size_t)deepest * pl.n + slot];
+        float4 a = gld(&pl.rec_a[(size_t)deepest * pl.n + slot]);
         L = add3(f3(0.0f, 0.0f, 0.0f), f3(a.x, a.y, a.z)); // final hit: direct light only (:316-319)
     }
     // The recursion is a serial chain, but its loads are not: the records (and material rows) of CRT_FINISH_PF vertices are
@@ -262,8 +277,8 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
 #pragma unroll
         for (int j = 0; j < CRT_FINISH_PF; j++) {
             const int vj = v - j > 0 ? v - j : 0;
-            a[j] = pl.rec_a[(size_t)vj * pl.n + slot];
-            mat[j] = __float_as_uint(pl.rec_b[(size_t)vj * pl.n + slot].w);
+            a[j] = gld(&pl.rec_a[(size_t)vj * pl.n + slot]);
+            mat[j] = __float_as_uint(gld(&pl.rec_b[(size_t)vj * pl.n + slot]).w);
         }
 #pragma unroll
         for (int j = 0; j < CRT_FINISH_PF; j++) fm[j] = mat_row(tb, mat[j], 0);
@@ -1126,13 +1141,13 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // The phase is a chain of dependent loads (path planes -> triangle / material / light tables -> light triangle), and a wave
     // that waits issues nothing: everything whose address is known is fetched up front, needed by this lane's stage or not.
     //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
-    const float4 la = pl.la[g];
-    const uint4 idv = pl.id[g];
-    const float4 vn = pl.vn[g];
-    const float4 cc = pl.cc[g]; // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
+    const float4 la = gld(&pl.la[g]);
+    const uint4 idv = gld(&pl.id[g]);
+    const float4 vn = gld(&pl.vn[g]);
+    const float4 cc = gld(&pl.cc[g]); // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
     const int res_tri = __float_as_int(qb.w);
-    const float4 gq_hit = sc.tri_nm[res_tri >= 0 ? res_tri : 0];
+    const float4 gq_hit = gld(&sc.tri_nm[res_tri >= 0 ? res_tri : 0]);
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     //   round 2: material rows of the vertex the samples belong to after this visit (the new one for ST_HIT), row 1 of the
@@ -1145,7 +1160,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     const uint32_t n_nee = (uint32_t)(sc.n_lights * P.lsn);
     const uint32_t q_next = stage == ST_SHADOW ? (st >> 16) + 1 : 0u;
     uint4 lg_next = make_uint4(0u, 1u, 0u, 0u);
-    if (n_nee > 0) lg_next = tb.lights[fast_div(q_next < n_nee ? q_next : 0u, P.lsn_div.m, P.lsn_div.sh)];
+    if (n_nee > 0) lg_next = gld(&tb.lights[fast_div(q_next < n_nee ? q_next : 0u, P.lsn_div.m, P.lsn_div.sh)]);
     Lane s;
     s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
     s.Ld = f3(la.x, la.y, la.z);
@@ -1169,10 +1184,10 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             const F3 pn = s.nrm;
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
             cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
-            pl.rec_a[pr].w = cos_prev;
+            gst(&pl.rec_a[pr].w, cos_prev);
             if (__float_as_uint(pm1_old.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
                 const float ns = mat_row(tb, s.mat, 0).w;
-                const float4 pb = pl.rec_b[pr]; // direction that arrived at the previous vertex
+                const float4 pb = gld(&pl.rec_b[pr]); // direction that arrived at the previous vertex
                 const float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
                 const F3 in = unit3(f3(pb.x, pb.y, pb.z));
                 const F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
@@ -1181,19 +1196,19 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
                 const U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
                 const F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
                 // the probe leaves from prev.pos (= this ray's origin); the bounce direction waits in rec_b[depth]
-                pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f);
-                pl.vx[g] = make_float4(pos.x, pos.y, pos.z, __int_as_float(res_tri));
-                pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_PROBE << 8) | (s.q << 16)));
+                gst(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f));
+                gst(&pl.vx[g], make_float4(pos.x, pos.y, pos.z, __int_as_float(res_tri)));
+                gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_PROBE << 8) | (s.q << 16))));
                 nr.o = s.ro; nr.d = unit3(refd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = RF_PROBE;
                 return PH3_NONE;
             }
         }
         s.pos = pos; s.vtri = (uint32_t)res_tri;
     } else { // ST_PROBE: the probe ray of vertex depth-1 (Render.cuh:304-313); vn still describes that vertex
-        const float4 vx = pl.vx[g];
+        const float4 vx = gld(&pl.vx[g]);
         s.pos = f3(vx.x, vx.y, vx.z); s.vtri = __float_as_uint(vx.w);
         if (res_tri >= 0) {
-            const int hmat = sc.tri_mat[res_tri];
+            const int hmat = gld(&sc.tri_mat[res_tri]);
             const float4 h1 = mat_row(tb, hmat, 1);
             if (__float_as_uint(h1.w) & 1u) {
                 const float4 h2 = mat_row(tb, hmat, 2);
@@ -1209,34 +1224,34 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
                 // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
                 const F3 kekd = mul3(f3(h2.x, h2.y, h2.z), f3(pm1.x, pm1.y, pm1.z));
                 const F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
-                float4 a = pl.rec_a[pr];
+                float4 a = gld(&pl.rec_a[pr]);
                 a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
-                pl.rec_a[pr] = a;
+                gst(&pl.rec_a[pr], a);
             }
         }
-        const float4 pb = pl.rec_b[(size_t)s.depth * pl.n + g]; // the bounce direction that found the current vertex
+        const float4 pb = gld(&pl.rec_b[(size_t)s.depth * pl.n + g]); // the bounce direction that found the current vertex
         s.rd = f3(pb.x, pb.y, pb.z);
         do_enter = true;
     }
     if (do_enter) { // a new vertex (pos, vtri) at `depth`, reached along s.rd
         float4 gq = gq_hit;
         if (stage == ST_PROBE) { // the vertex was found by the ray before the probe: its triangle waits in the vx plane
-            gq = sc.tri_nm[s.vtri];
+            gq = gld(&sc.tri_nm[s.vtri]);
             m0_cur = mat_row(tb, __float_as_uint(gq.w), 0); m1_cur = mat_row(tb, __float_as_uint(gq.w), 1);
         }
         s.nrm = f3(gq.x, gq.y, gq.z);
         s.mat = __float_as_uint(gq.w);
-        pl.rec_b[(size_t)s.depth * pl.n + g] = make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat));
-        pl.vx[g] = make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri));
-        pl.vn[g] = make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat));
+        gst(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
+        gst(&pl.vx[g], make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri)));
+        gst(&pl.vn[g], make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat)));
         if (__float_as_uint(m1_cur.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
-            pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16)));
+            gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16))));
             return PH3_LC;
         }
         s.Ld = f3(0.0f, 0.0f, 0.0f);
         s.q = 0;
         if (n_nee == 0) {
-            pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
+            gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8))));
             return PH3_LB;
         }
     }
@@ -1264,12 +1279,12 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         cnt.rays++; cnt.shadow++;
         s.q++;
         if (s.q == n_nee) { // that was the last sample of the vertex: on to the roulette
-            pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8)));
+            gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8))));
             return PH3_LB;
         }
     }
-    pl.la[g] = make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16)));
-    pl.cc[g] = make_float4(s.c.x, s.c.y, s.c.z, s.tl);
+    gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16))));
+    gst(&pl.cc[g], make_float4(s.c.x, s.c.y, s.c.z, s.tl));
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
     nr.flags = RF_SHADOW | (s.q + 1 == n_nee ? RF_LAST : 0u) | (skip ? RF_SKIP : 0u);
     return PH3_NONE;
@@ -1280,9 +1295,9 @@ template <int MODE>
 __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const Pool& pl = P.pool;
-    const float4 la = pl.la[g];
-    const uint4 idv = pl.id[g];
-    const float4 cc = pl.cc[g]; // (with the other planes, not after the stage is known: one round trip less, see logic_A)
+    const float4 la = gld(&pl.la[g]);
+    const uint4 idv = gld(&pl.id[g]);
+    const float4 cc = gld(&pl.cc[g]); // (with the other planes, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     uint32_t depth = st & 255u;
@@ -1290,7 +1305,7 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
         if (!shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w))) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
-    pl.rec_a[(size_t)depth * pl.n + g] = make_float4(Ld.x, Ld.y, Ld.z, 0.0f);
+    gst(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, 0.0f));
     bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
     U4 rb;
     rb.x = rb.y = rb.z = rb.w = 0;
@@ -1299,13 +1314,13 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
         stop = rng_uniform(rb.x) > P.p_rr;
     }
     if (stop) {
-        pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8)));
+        gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8))));
         return PH3_LC;
     }
-    const float4 vn = pl.vn[g], vx = pl.vx[g];
+    const float4 vn = gld(&pl.vn[g]), vx = gld(&pl.vx[g]);
     const F3 ndir = unit3(sample_hemisphere(f3(vn.x, vn.y, vn.z), rng_uniform(rb.y), rng_uniform(rb.z)));
     depth++;
-    pl.la[g] = make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8)));
+    gst(&pl.la[g], make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8))));
     nr.o = f3(vx.x, vx.y, vx.z); nr.d = unit3(ndir); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
     return PH3_NONE;
 }
@@ -1315,8 +1330,8 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
 __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr)
 {
     const Pool& pl = P.pool;
-    const float4 la = pl.la[g];
-    const uint4 idv = pl.id[g]; // (with la, not after the stage is known: one round trip less, see logic_A)
+    const float4 la = gld(&pl.la[g]);
+    const uint4 idv = gld(&pl.id[g]); // (with la, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
@@ -1330,7 +1345,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
     const uint32_t grank_ = (uint32_t)__popcll(gmask_ & ((1ull << lane_) - 1ull));
     unsigned int pre_base_ = 0;
     const bool pre_ok_ = lo_ < P.n_items;
-    if (pre_ok_ && lane_ == __ffsll((long long)gmask_) - 1) pre_base_ = atomicAdd(P.item_next + home_ * ITEM_STRIDE, (unsigned int)__popcll(gmask_));
+    if (pre_ok_ && lane_ == __ffsll((long long)gmask_) - 1) pre_base_ = __hip_atomic_fetch_add((CRT_GAS unsigned int*)(P.item_next + home_ * ITEM_STRIDE), (unsigned int)__popcll(gmask_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (stage != ST_NEW) {
         int deepest = (int)depth;
         bool emissive = false;
@@ -1338,15 +1353,15 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         if (stage == ST_HIT) deepest = (int)depth - 1; // the ray that looked for vertex `depth` missed (Render.cuh:210)
         else if ((st >> 16) & 1u) {
             emissive = true;
-            const float4 m2 = mat_row(tb, __float_as_uint(pl.vn[g].w), 2);
+            const float4 m2 = mat_row(tb, __float_as_uint(gld(&pl.vn[g]).w), 2);
             ke = f3(m2.x, m2.y, m2.z);
         }
         const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
         // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
         // and the scene in L2
-        __builtin_nontemporal_store(L.x, &P.L[idv.z].x);
-        __builtin_nontemporal_store(L.y, &P.L[idv.z].y);
-        __builtin_nontemporal_store(L.z, &P.L[idv.z].z);
+        __builtin_nontemporal_store(L.x, (CRT_GAS float*)&P.L[idv.z].x);
+        __builtin_nontemporal_store(L.y, (CRT_GAS float*)&P.L[idv.z].y);
+        __builtin_nontemporal_store(L.z, (CRT_GAS float*)&P.L[idv.z].z);
     }
     bool first_ = pre_ok_;
     for (;;) {
@@ -1362,13 +1377,13 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
             const uint32_t sh_ = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh);
             const uint32_t slo_ = sh_ * P.items_per_shard, shi_ = min(slo_ + P.items_per_shard, P.n_items);
             const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
-            if (item >= wlo_) item = P.item_list[sh_ * P.order_window + (item - wlo_)];
+            if (item >= wlo_) item = gld(&P.item_list[sh_ * P.order_window + (item - wlo_)]);
         }
         bool valid; uint32_t pi, pj, pixel_index, k;
         decode_item(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
         cnt.paths++;
-        pl.id[g] = make_uint4(pixel_index, k, item, 0u);
+        gst(&pl.id[g], make_uint4(pixel_index, k, item, 0u));
         const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
         const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
         const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
@@ -1376,7 +1391,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         const F3 wd = f3(P.inv_view[0] * cd.x + (P.inv_view[3] * cd.y + P.inv_view[6] * cd.z),
                          P.inv_view[1] * cd.x + (P.inv_view[4] * cd.y + P.inv_view[7] * cd.z),
                          P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
-        pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8));
+        gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8)));
         nr.o = f3(P.eye[0], P.eye[1], P.eye[2]); nr.d = unit3(wd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
         return true;
     }
@@ -1388,14 +1403,14 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
 __device__ __forceinline__ bool query_C(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const Pool& pl = P.pool;
-    const float4 la = pl.la[g];
-    const uint4 idv = pl.id[g];
-    if (((__float_as_uint(la.w) >> 8) & 15u) != ST_NEW) P.L[idv.z] = make_float4(qa.w, qb.w, 0.0f, 0.0f);
+    const float4 la = gld(&pl.la[g]);
+    const uint4 idv = gld(&pl.id[g]);
+    if (((__float_as_uint(la.w) >> 8) & 15u) != ST_NEW) gst(&P.L[idv.z], make_float4(qa.w, qb.w, 0.0f, 0.0f));
     const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
     if (item == ITEM_NONE) return false;
-    pl.id[g] = make_uint4(0u, 0u, item, 0u);
-    pl.la[g] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8));
-    const float4 o = P.q_o[item], d = P.q_d[item];
+    gst(&pl.id[g], make_uint4(0u, 0u, item, 0u));
+    gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8)));
+    const float4 o = gld(&P.q_o[item]), d = gld(&P.q_d[item]);
     nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = o.w; nr.kind = __float_as_uint(d.w); nr.flags = RF_QUERY;
     return true;
 }
