@@ -253,6 +253,30 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
     setup_shadow_lg(P, s, f_r, gld(&tb.lights[fast_div(s.q, P.lsn_div.m, P.lsn_div.sh)]));
 }
 
+// The id plane of a path: (pixel index, sample, work item, -).  -DCRT_ID_ITEM_ONLY (experiment): the plane holds the work
+// item alone (4 B instead of 16) and pixel / sample are worked out from it again wherever they are needed.
+__device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
+{
+#ifdef CRT_ID_ITEM_ONLY
+    const uint32_t item = gld((const uint32_t*)P.pool.id + g);
+    uint32_t pixel_index, k, pi, pj;
+    bool valid;
+    decode_item(P, item, pixel_index, k, valid, pi, pj);
+    return make_uint4(pixel_index, k, item, 0u);
+#else
+    return gld(&P.pool.id[g]);
+#endif
+}
+__device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t pixel_index, const uint32_t k, const uint32_t item)
+{
+#ifdef CRT_ID_ITEM_ONLY
+    (void)pixel_index; (void)k;
+    *(CRT_GAS uint32_t*)((uint32_t*)P.pool.id + g) = item;
+#else
+    gst(&P.pool.id[g], make_uint4(pixel_index, k, item, 0u));
+#endif
+}
+
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
 template <bool LDS_TABLES>
 __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TABLES>& tb, uint32_t slot, int deepest, bool emissive, F3 ke)
@@ -1142,7 +1166,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // that waits issues nothing: everything whose address is known is fetched up front, needed by this lane's stage or not.
     //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = gld(&pl.id[g]);
+    const uint4 idv = load_path_id(P, g);
     const float4 vn = gld(&pl.vn[g]);
     const float4 cc = gld(&pl.cc[g]); // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
@@ -1296,7 +1320,7 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
 {
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = gld(&pl.id[g]);
+    const uint4 idv = load_path_id(P, g);
     const float4 cc = gld(&pl.cc[g]); // (with the other planes, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
@@ -1331,7 +1355,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
 {
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = gld(&pl.id[g]); // (with la, not after the stage is known: one round trip less, see logic_A)
+    const uint4 idv = load_path_id(P, g); // (with la, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
@@ -1383,7 +1407,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         decode_item(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
         cnt.paths++;
-        gst(&pl.id[g], make_uint4(pixel_index, k, item, 0u));
+        store_path_id(P, g, pixel_index, k, item);
         const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
         const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
         const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
@@ -1404,11 +1428,11 @@ __device__ __forceinline__ bool query_C(const LParams& P, const uint32_t g, cons
 {
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = gld(&pl.id[g]);
+    const uint4 idv = load_path_id(P, g);
     if (((__float_as_uint(la.w) >> 8) & 15u) != ST_NEW) gst(&P.L[idv.z], make_float4(qa.w, qb.w, 0.0f, 0.0f));
     const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
     if (item == ITEM_NONE) return false;
-    gst(&pl.id[g], make_uint4(0u, 0u, item, 0u));
+    store_path_id(P, g, 0u, 0u, item);
     gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8)));
     const float4 o = gld(&P.q_o[item]), d = gld(&P.q_d[item]);
     nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = o.w; nr.kind = __float_as_uint(d.w); nr.flags = RF_QUERY;
@@ -1600,6 +1624,10 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     if (STATS) tc.inner++;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
     slab_quad_pruned<SORT>(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3); // (SORT == pruning mode: CRT_SORT4)
+    // (all four entry distances exist before the exchanges and pushes begin: left alone the compiler starts pushing the first pair's
+    // loser while the second pair's boxes are still being computed, splits the arithmetic over two blocks and rebuilds the
+    // broadcast operand pairs of the packed instructions in the second one -- nine extra moves per step)
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     const float inf = pinf();
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
     // ascending by entry distance: (0,1)(2,3)(0,2)(1,3)(1,2)
