@@ -253,28 +253,21 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
     setup_shadow_lg(P, s, f_r, gld(&tb.lights[fast_div(s.q, P.lsn_div.m, P.lsn_div.sh)]));
 }
 
-// The id plane of a path: (pixel index, sample, work item, -).  -DCRT_ID_ITEM_ONLY (experiment): the plane holds the work
-// item alone (4 B instead of 16) and pixel / sample are worked out from it again wherever they are needed.
+// The id plane of a path in k_mega3 is its work item alone (4 B); pixel and sample are worked out from it again wherever they are
+// needed (two multiply-shift divisions and the tile arithmetic).  Against keeping (pixel, sample, item) as 16 B, measured on C2 with
+// one --pmc pass per counter: memory-side traffic 431.7 -> 382.7 GB per launch, L2 miss rate 0.495 -> 0.467, vector instructions
+// + 1.2 %, frame 96.7 -> 95.5 ms (profiles/r03_traffic_id_plane.txt).  (The wavefront pipeline keeps the 16-byte entries.)
 __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
 {
-#ifdef CRT_ID_ITEM_ONLY
     const uint32_t item = gld((const uint32_t*)P.pool.id + g);
     uint32_t pixel_index, k, pi, pj;
     bool valid;
     decode_item(P, item, pixel_index, k, valid, pi, pj);
     return make_uint4(pixel_index, k, item, 0u);
-#else
-    return gld(&P.pool.id[g]);
-#endif
 }
-__device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t pixel_index, const uint32_t k, const uint32_t item)
+__device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t item)
 {
-#ifdef CRT_ID_ITEM_ONLY
-    (void)pixel_index; (void)k;
     *(CRT_GAS uint32_t*)((uint32_t*)P.pool.id + g) = item;
-#else
-    gst(&P.pool.id[g], make_uint4(pixel_index, k, item, 0u));
-#endif
 }
 
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
@@ -1407,7 +1400,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
         decode_item(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
         cnt.paths++;
-        store_path_id(P, g, pixel_index, k, item);
+        store_path_id(P, g, item);
         const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
         const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
         const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
@@ -1432,7 +1425,7 @@ __device__ __forceinline__ bool query_C(const LParams& P, const uint32_t g, cons
     if (((__float_as_uint(la.w) >> 8) & 15u) != ST_NEW) gst(&P.L[idv.z], make_float4(qa.w, qb.w, 0.0f, 0.0f));
     const uint32_t item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
     if (item == ITEM_NONE) return false;
-    store_path_id(P, g, 0u, 0u, item);
+    store_path_id(P, g, item);
     gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8)));
     const float4 o = gld(&P.q_o[item]), d = gld(&P.q_d[item]);
     nr.o = f3(o.x, o.y, o.z); nr.d = f3(d.x, d.y, d.z); nr.tl = o.w; nr.kind = __float_as_uint(d.w); nr.flags = RF_QUERY;
