@@ -148,14 +148,16 @@ typedef struct {
     uint64_t inner_pops, leaf_pops, tri_tests, hits; /* visit counters of the traversal that ran; CRT_FLAG_STATS only
                                                          (with CRT_TRAVERSAL_REFERENCE: the reference's visit set) */
     uint64_t stack_sum, stack_max;                   /* CRT_FLAG_STATS: sum / max over rays of the traversal stack high-water */
-    uint64_t phase_cycles[24];                       /* diagnostic builds (-DCRT_STAMPS) only: wave cycles in logic / leaf / inner / other, then
-                                                        iterations[3], gathered rays[3] (logic, inner, leaf), logic section passes[8], section lanes[6] */
-    float kernel_ms;             /* sum of the HIP-event times of the traversal kernel (k_trace) launches */
-    float logic_ms;              /* sum of the HIP-event times of the path-logic kernel (k_logic) launches */
-    float total_ms;              /* HIP-event time of the whole device pipeline of this call */
-    uint32_t kernel_launches;    /* number of k_trace launches */
+    uint64_t phase_cycles[24];                       /* reserved (zero): the per-phase cycle stamps of rounds 1-2 were replaced by the
+                                                        basic-block profile of tools/bbprof */
+    float kernel_ms;             /* sum of the HIP-event times of the render kernel's launches: k_mega3, one launch per chunk of at most
+                                    2^30 work items (the wavefront fallback pipeline: the k_trace launches) */
+    float logic_ms;              /* 0 for k_mega3 (the path logic is fused into it); the wavefront fallback: the k_logic launches */
+    float total_ms;              /* HIP-event time of the whole device pipeline of this call (k_order_items, k_mega3, k_accumulate) */
+    uint32_t kernel_launches;    /* number of k_mega3 (fallback: k_trace) launches */
     uint64_t rays_untraced;      /* of `shadow_rays`: next-event samples whose contribution is exactly zero (clamped cosine, black
-                                    BSDF), answered without traversal by CRT_TRAVERSAL_FAST -- adding +0 cannot change L_dir */
+                                    BSDF), answered without traversal by CRT_TRAVERSAL_EXACT / _FAST -- adding +0 cannot change L_dir;
+                                    0 with CRT_FLAG_TRACE_ALL or CRT_TRAVERSAL_REFERENCE */
 } crt_stats;
 
 /* ------------------------------------------------------------------------
