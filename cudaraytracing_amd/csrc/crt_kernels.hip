@@ -1489,14 +1489,12 @@ template <bool PRUNE = true>
 __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
                                                  const F3 o, const F3 inv, const float bound, float& t0, float& t1, float& t2, float& t3)
 {
-    // EXPERIMENT (timing only, NOT exact): one fused multiply-add per plane pair, (plane * inv) - o * inv
-    const v2f cx = v2s(-(o.x * inv.x)), cy = v2s(-(o.y * inv.y)), cz = v2s(-(o.z * inv.z));
-    const v2f nxa = __builtin_elementwise_fma(v2(nx.x, nx.y), v2s(inv.x), cx), nxb = __builtin_elementwise_fma(v2(nx.z, nx.w), v2s(inv.x), cx);
-    const v2f nya = __builtin_elementwise_fma(v2(ny.x, ny.y), v2s(inv.y), cy), nyb = __builtin_elementwise_fma(v2(ny.z, ny.w), v2s(inv.y), cy);
-    const v2f nza = __builtin_elementwise_fma(v2(nz.x, nz.y), v2s(inv.z), cz), nzb = __builtin_elementwise_fma(v2(nz.z, nz.w), v2s(inv.z), cz);
-    const v2f fxa = __builtin_elementwise_fma(v2(fx.x, fx.y), v2s(inv.x), cx), fxb = __builtin_elementwise_fma(v2(fx.z, fx.w), v2s(inv.x), cx);
-    const v2f fya = __builtin_elementwise_fma(v2(fy.x, fy.y), v2s(inv.y), cy), fyb = __builtin_elementwise_fma(v2(fy.z, fy.w), v2s(inv.y), cy);
-    const v2f fza = __builtin_elementwise_fma(v2(fz.x, fz.y), v2s(inv.z), cz), fzb = __builtin_elementwise_fma(v2(fz.z, fz.w), v2s(inv.z), cz);
+    const v2f nxa = (v2(nx.x, nx.y) - v2s(o.x)) * v2s(inv.x), nxb = (v2(nx.z, nx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f nya = (v2(ny.x, ny.y) - v2s(o.y)) * v2s(inv.y), nyb = (v2(ny.z, ny.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f nza = (v2(nz.x, nz.y) - v2s(o.z)) * v2s(inv.z), nzb = (v2(nz.z, nz.w) - v2s(o.z)) * v2s(inv.z);
+    const v2f fxa = (v2(fx.x, fx.y) - v2s(o.x)) * v2s(inv.x), fxb = (v2(fx.z, fx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f fya = (v2(fy.x, fy.y) - v2s(o.y)) * v2s(inv.y), fyb = (v2(fy.z, fy.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f fza = (v2(fz.x, fz.y) - v2s(o.z)) * v2s(inv.z), fzb = (v2(fz.z, fz.w) - v2s(o.z)) * v2s(inv.z);
     const float e0 = fmax3(nxa.x, nya.x, nza.x), e1 = fmax3(nxa.y, nya.y, nza.y), e2 = fmax3(nxb.x, nyb.x, nzb.x), e3 = fmax3(nxb.y, nyb.y, nzb.y);
     const float x0 = fmin3(fxa.x, fya.x, fza.x), x1 = fmin3(fxa.y, fya.y, fza.y), x2 = fmin3(fxb.x, fyb.x, fzb.x), x3 = fmin3(fxb.y, fyb.y, fzb.y);
     const float inf = pinf();
