@@ -98,7 +98,35 @@ __device__ __forceinline__ F3 sub3(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y,
 __device__ __forceinline__ F3 mul3(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
 __device__ __forceinline__ F3 scale3(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }   // v * s
 __device__ __forceinline__ F3 scalel3(float s, F3 a) { return f3(s * a.x, s * a.y, s * a.z); }  // s * v
-__device__ __forceinline__ F3 div3(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+// ---- three quotients by one positive divisor, bit for bit the IEEE quotients (a.x / n, a.y / n, a.z / n), in 12 instructions + a guard
+// instead of the 30 of three division expansions.  y = 1 / n by v_rcp_f32 + one Newton step (the correctly rounded reciprocal:
+// crt_device_rcp_check, all 2^32 inputs), then Markstein's correction: q0 = a y, r = fma(n, q0, -a), q = fma(-r, y, q0).  That this IS
+// the IEEE quotient was checked for ALL 2^23 x 2^23 pairs of mantissas on gfx950 (tools/exhaustive/div_pair_check.hip,
+// profiles/r03_div_pair_check.txt: 7.04e13 pairs, 0 mismatches); scaling numerator and divisor by powers of two scales every
+// intermediate exactly while nothing leaves the normal range, which the guard ensures: 2^-62 <= n < 2^60 and every numerator zero
+// or 2^-64 <= |a| < 2^62 -- then 2^-124 < |a / n| < 2^124, and the residual, a multiple of 2^(exponent(a) - 47), is representable.
+// (The residual is formed with the opposite sign so that a zero numerator keeps its sign.)  Lanes outside the guard -- zero, negative
+// or non-finite divisors, tiny, huge or non-finite numerators -- take the division itself behind a wave-uniform branch.
+// `bounded`: the caller knows |a| <= n (1 + 2^-22) (normalisation): the upper test of the numerators is implied by the divisor's.
+__device__ __forceinline__ F3 quot3_exact(const F3 a, const float n, const bool bounded)
+{
+    const float y0 = __builtin_amdgcn_rcpf(n);
+    const float y = __builtin_fmaf(__builtin_fmaf(-n, y0, 1.0f), y0, y0);
+    const float qx = a.x * y, qy = a.y * y, qz = a.z * y;
+    F3 q = f3(__builtin_fmaf(-__builtin_fmaf(n, qx, -a.x), y, qx), __builtin_fmaf(-__builtin_fmaf(n, qy, -a.y), y, qy),
+              __builtin_fmaf(-__builtin_fmaf(n, qz, -a.z), y, qz));
+    asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z)); // (keeps the short form ahead of the branch instead of in an else-arm)
+    const uint32_t ex = f2u(a.x) & 0x7fffffffu, ey = f2u(a.y) & 0x7fffffffu, ez = f2u(a.z) & 0x7fffffffu;
+    // zero -> 0xffffffff: passes the lower test; anything else below 2^-64 fails it
+    const uint32_t lo = min(min(ex - 1u, ey - 1u), ez - 1u);
+    bool ok = (f2u(n) - 0x20800000u /* 2^-62 */ < 0x5d800000u - 0x20800000u /* .. 2^60 */) & (lo >= 0x1f800000u /* 2^-64 */ - 1u);
+    if (!bounded) ok = ok & (max(max(ex, ey), ez) < 0x5e800000u /* 2^62 */);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0, 0)) {
+        if (!ok) q = f3(a.x / n, a.y / n, a.z / n);
+    }
+    return q;
+}
+__device__ __forceinline__ F3 div3(F3 a, float s) { return quot3_exact(a, s, false); }
 // Eigen reduction order: p0 + (p1 + p2)
 __device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 __device__ __forceinline__ F3 cross3(F3 a, F3 b)
@@ -109,7 +137,7 @@ __device__ __forceinline__ float norm3(F3 a) { return sqrt_f(dot3(a, a)); }
 __device__ __forceinline__ F3 unit3(F3 a)
 {
     float z = dot3(a, a);
-    if (z > 0.0f) { float s = sqrt_f(z); return f3(a.x / s, a.y / s, a.z / s); }
+    if (z > 0.0f) { float s = sqrt_f(z); return quot3_exact(a, s, true); } // (|a| <= |a|: the divisor bounds the numerators)
     return a;
 }
 __device__ __forceinline__ float maxf_ref(float x, float y) { return x > y ? x : y; } // Global.h:111-114

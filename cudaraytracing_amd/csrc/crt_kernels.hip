@@ -2160,6 +2160,8 @@ __global__ void k_math(int fn, uint32_t n, const float* a, const float* b, float
     case 8: r = rng_uniform(__float_as_uint(x)); break;
     case 9: { float s, c; det_sincosf(x, &s, &c); r = s; break; }
     case 10: { float s, c; det_sincosf(x, &s, &c); r = c; break; }
+    case 11: r = quot3_exact(f3(x, x, x), y, false).y; break;              // the short exact division against x / y (tests)
+    case 12: r = quot3_exact(f3(x, 0.0f, -0.0f), y, true).x; break;        // ... in the form unit3 uses
     default: r = qnan();
     }
     out[i] = r;
@@ -3490,9 +3492,9 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
 int crt_device_math(int device, const char* fn, uint32_t n, const float* a, const float* b, float* out)
 {
     if (!fn || !a || !out) return fail(CRT_ERR_INVALID_ARG, "crt_device_math: null argument");
-    static const char* names[] = {"sin", "cos", "tan", "acos", "atan2", "exp", "log10", "pow", "uniform", "sincos_s", "sincos_c"};
+    static const char* names[] = {"sin", "cos", "tan", "acos", "atan2", "exp", "log10", "pow", "uniform", "sincos_s", "sincos_c", "div_short", "div_short_bounded"};
     int id = -1;
-    for (int i = 0; i < 11; i++)
+    for (int i = 0; i < 13; i++)
         if (std::strcmp(fn, names[i]) == 0) id = i;
     if (id < 0) return fail(CRT_ERR_INVALID_ARG, std::string("crt_device_math: unknown function ") + fn);
     if (n == 0) return CRT_OK;

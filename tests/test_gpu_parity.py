@@ -70,6 +70,36 @@ def test_short_reciprocal_is_the_division_for_every_input():
     assert outside > 0  # (zero / denormal / huge / infinite inputs do differ: the guard is not vacuous)
 
 
+def test_short_division_is_the_ieee_quotient():
+    """unit3 / div3 of the kernels divide three numerators by one positive divisor as an exact reciprocal plus Markstein's correction
+    (crt_device.h: quot3_exact; all 2^46 mantissa pairs were checked on gfx950 by tools/exhaustive/div_pair_check.hip) inside an
+    exponent guard, the IEEE division outside it.  Here: the entry point against numpy's float32 division, bit for bit, on random
+    operands over the whole exponent range, on the guard's borders, zeros of both signs, denormals, infinities and NaNs."""
+    rng = np.random.default_rng(11)
+    def bits(u):
+        return np.asarray(u, dtype=np.uint32).view(np.float32)
+    a = [bits(rng.integers(0, 2**32, 400000, dtype=np.uint64).astype(np.uint32)),            # anything, incl. NaN / inf / denormals
+         (rng.standard_normal(400000) * np.exp2(rng.integers(-70, 70, 400000))).astype(np.float32)]
+    b = [bits(rng.integers(0, 2**32, 400000, dtype=np.uint64).astype(np.uint32)),
+         np.abs(rng.standard_normal(400000) * np.exp2(rng.integers(-70, 70, 400000))).astype(np.float32)]
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 2.0**-64, np.nextafter(np.float32(2.0**-64), np.float32(0)), 2.0**62, np.nextafter(np.float32(2.0**62), np.float32(0)),
+                     2.0**-62, 2.0**60, 1e-45, -1e-45, 1e-38, 3.4e38, np.inf, -np.inf, np.nan, 0.6, 1.0 / 3.0, 16777215.0], dtype=np.float32)
+    ea, eb = np.meshgrid(edge, edge)
+    a.append(ea.reshape(-1).copy()); b.append(eb.reshape(-1).copy())
+    a, b = np.concatenate(a), np.concatenate(b)
+    with np.errstate(all="ignore"):
+        ref = (a / b).astype(np.float32)
+    for fn in ("div_short", "div_short_bounded"):
+        aa, bb, rr = a, b, ref
+        if fn == "div_short_bounded":   # the form unit3 uses relies on |numerator| <= divisor (a component of v over |v|)
+            keep = ~(np.abs(a) > np.abs(b))
+            aa, bb, rr = a[keep], b[keep], ref[keep]
+        got = crt.device_math(fn, aa, bb)
+        same = (got.view(np.uint32) == rr.view(np.uint32)) | (np.isnan(got) & np.isnan(rr))
+        assert same.all(), (fn, aa[~same][:5], bb[~same][:5], got[~same][:5], rr[~same][:5])
+        assert len(aa) > 300000
+
+
 def test_device_philox_matches_oracle_and_kat():
     ctr = np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32)
     key = np.array([[0, 0], [0xFFFFFFFF] * 2, [0xA4093822, 0x299F31D0]], dtype=np.uint32)
