@@ -27,8 +27,10 @@ Three candidate bounds are priced, each with a fraction <= 1 by construction, an
 `roofline.frac` / `roofline.bound`:
     hbm        memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md
                prescribes) / t against 8 TB/s;
-    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / (cycles per wave64 VALU instruction with four waves per
-               SIMD, tools/valu_issue_bench.hip);
+    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / (cycles per wave64 VALU instruction of THIS kernel's mix: the exact
+               dynamic opcode census of tools/bbprof -- executions of every basic block of the production ISA -- priced with the
+               per-opcode issue costs of tools/valu_issue_gen.py, profiles/bbprof_latest.json, hash-stamped like the PMC file;
+               `frac_at_guide_peak` prices the same count at the guide's 2 cycles per instruction);
     l2         TCC requests x 128 B / t against the L2 peak.
 The SURVEY 8(d) contract figure -- algorithmic bytes of the REFERENCE traversal's visit set, B_ray = 64 x inner
 visits + 8 x leaf visits + 36 x triangle tests + 16 x hits, counted by the exhaustive kernel on a spp=8 slice --
