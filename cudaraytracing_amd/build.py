@@ -21,7 +21,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"] +
 DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
 LIB_SOURCES = ["crt_kernels.hip", "crt_multi.hip", "crt_bvh_build.hip", "crt_accel_build.hip", "crt_host.cpp"]
-LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", "crt_png.h", "crt_jpeg.h", "crt_image.h", "crt_bvh_build.h",
+LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", "crt_png.h", "crt_jpeg.h", "crt_formats.h", "crt_image.h", "crt_bvh_build.h",
                           os.path.join("..", "..", "include", "crt.h")]
 FLAGS_FILE = os.path.join(LIBDIR, "libcrt.flags")  # the flag string libcrt.so was built with (a variant build is stale for a default run)
 

@@ -777,15 +777,20 @@ int crt_inverse_view(const float eye[3], const float lookat[3], const float up[3
 int crt_image_load(const char* path, int32_t* x, int32_t* y, int32_t* comp, uint8_t* out, uint64_t cap)
 {
     if (!path || !x || !y || !comp) { g_last_error = "crt_image_load: null argument"; return CRT_ERR_INVALID_ARG; }
-    crtimg::Image img;
-    const std::string err = crtimg::load(path, img);
-    if (!err.empty()) { g_last_error = "crt_image_load: " + err; return err.rfind("cannot open", 0) == 0 ? CRT_ERR_IO : CRT_ERR_UNSUPPORTED; }
-    *x = img.width; *y = img.height; *comp = img.comp;
-    if (out) {
-        if (cap < img.px.size()) { g_last_error = "crt_image_load: buffer too small"; return CRT_ERR_INVALID_ARG; }
-        std::memcpy(out, img.px.data(), img.px.size());
+    try {
+        crtimg::Image img;
+        const std::string err = crtimg::load(path, img);
+        if (!err.empty()) { g_last_error = "crt_image_load: " + err; return err.rfind("cannot open", 0) == 0 ? CRT_ERR_IO : CRT_ERR_UNSUPPORTED; }
+        *x = img.width; *y = img.height; *comp = img.comp;
+        if (out) {
+            if (cap < img.px.size()) { g_last_error = "crt_image_load: buffer too small"; return CRT_ERR_INVALID_ARG; }
+            std::memcpy(out, img.px.data(), img.px.size());
+        }
+        return CRT_OK;
+    } catch (const std::bad_alloc&) { // (a file may honestly announce more pixels than the host has memory for)
+        g_last_error = "crt_image_load: out of host memory";
+        return CRT_ERR_OOM;
     }
-    return CRT_OK;
 }
 int crt_task_load(const char* path, crt_task* out)
 {

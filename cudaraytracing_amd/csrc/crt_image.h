@@ -2,19 +2,20 @@
 //
 // The reference decodes textures with its vendored stb_image: stbi_load(path, &height, &width, &channel, 0)
 // (include/Loader.h:58), i.e. 8-bit samples, top row first, the file's own channel count.  This header returns the same
-// (x, y, comp, samples) for the four formats a renderer's asset folder usually holds:
+// (x, y, comp, samples) for every format that decoder reads:
 //   PNG  own inflate / unfilter, plain and Adam7-interlaced (crt_png.h);
 //   JPEG baseline and progressive, stb_image's inverse DCT / upsampling / colour arithmetic (crt_jpeg.h);
 //   BMP  uncompressed: 1 / 4 / 8-bit palettes, 16-bit and 32-bit with channel masks (BI_BITFIELDS or the defaults), 24-bit;
 //        RLE and embedded PNG / JPEG are rejected as stb_image rejects them;
 //   TGA  types 1 / 2 / 3 and their run-length forms 9 / 10 / 11: 8-bit grey, 16-bit grey + alpha, 15 / 16-bit RGB (5-5-5),
-//        24 / 32-bit, colour-mapped with 8 or 16-bit indices; origin bit honoured.
-// GIF, PSD, PIC, PNM and Radiance HDR (the other formats of stb_image) are NOT decoded: CRT_ERR_UNSUPPORTED.
+//        24 / 32-bit, colour-mapped with 8 or 16-bit indices; origin bit honoured;
+//   GIF (first frame), PSD, Softimage PIC, binary PNM, Radiance HDR (crt_formats.h).
 // Pinned against the reference's own decoder: oracle/ref_probe/stb_probe.c compiles the vendored stb_image.h where it lies
 // and tests/golden/stb_decode.json holds what it returns for the fixture files of tests/golden/textures/.
 #ifndef CRT_IMAGE_H
 #define CRT_IMAGE_H
 
+#include "crt_formats.h"
 #include "crt_jpeg.h"
 #include "crt_png.h"
 
@@ -290,18 +291,24 @@ inline std::string load(const std::string& path, Image& img)
         const std::string e = load_bmp(b, img);
         return e.empty() ? e : e + ": " + path;
     }
-    if (crtjpg::looks_like_jpeg(d)) {
-        const std::string e = crtjpg::decode(d, img);
+    // (the order of the reference's decoder: PNG, BMP, GIF, PSD, PIC, JPEG, PNM, HDR and TGA last, stb_image.h:1136-1185)
+    typedef std::string (*Loader)(const std::vector<uint8_t>&, Image&);
+    Loader other = nullptr;
+    if (starts("GIF87a", 6) || starts("GIF89a", 6)) other = crtfmt::load_gif;
+    else if (starts("8BPS", 4)) other = crtfmt::load_psd;
+    else if (crtfmt::looks_like_pic(d)) other = crtfmt::load_pic;
+    else if (crtjpg::looks_like_jpeg(d)) other = crtjpg::decode;
+    else if (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) other = crtfmt::load_pnm;
+    else if (crtfmt::looks_like_hdr(d)) other = crtfmt::load_hdr;
+    if (other) {
+        const std::string e = other(d, img);
         return e.empty() ? e : e + ": " + path;
     }
-    const char* other = starts("GIF8", 4) ? "GIF" : starts("8BPS", 4) ? "PSD" : starts("#?RADIANCE", 10) || starts("#?RGBE", 6) ? "Radiance HDR"
-                        : starts("\x53\x80\xf6\x34", 4) ? "PIC" : (d.size() > 2 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) ? "PNM" : nullptr;
-    if (other) return std::string(other) + " textures are not decoded by this build (PNG, JPEG, BMP and TGA are): " + path;
     if (looks_like_tga(b)) {
         const std::string e = load_tga(b, img);
         return e.empty() ? e : e + ": " + path;
     }
-    return "unknown texture format (PNG, JPEG, BMP and TGA are decoded): " + path;
+    return "unknown texture format (PNG, JPEG, BMP, TGA, GIF, PSD, PIC, PNM and Radiance HDR are decoded): " + path;
 }
 
 } // namespace crtimg

@@ -209,8 +209,19 @@ inline std::string load(const std::string& path, Image& img)
     // raw sample values (up to 16 bits) of the whole image, samp[(y * w + x) * chans + c]: filled pass by pass.  A non-interlaced
     // file is one pass over every pixel; an Adam7 file (stb_image.h:5116-5150 reads them too) is seven reduced images, each with
     // its own filtered scan lines, whose pixels land at (x0 + i * dx, y0 + j * dy).
-    std::vector<uint16_t> samp((size_t)w * h * chans);
     static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    {   // the data stream must hold every scan line of every pass BEFORE the image is allocated (a damaged header may say 2^24 x 2^24)
+        uint64_t need = 0;
+        for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
+            const uint32_t x0 = interlace ? ax0[pass] : 0, y0 = interlace ? ay0[pass] : 0, dx = interlace ? adx[pass] : 1, dy = interlace ? ady[pass] : 1;
+            if (x0 >= w || y0 >= h) continue;
+            const uint64_t pw = (w + dx - 1 - x0) / dx, ph = (h + dy - 1 - y0) / dy;
+            need += ((pw * bpp_bits + 7) / 8 + 1) * ph;
+        }
+        if ((uint64_t)raw.size() < need) return "short PNG data stream in " + path;
+        if ((uint64_t)w * h * (uint64_t)chans > 0x7fffffffull) return "PNG too large: " + path; // (the reference's decoder: sizes are ints)
+    }
+    std::vector<uint16_t> samp((size_t)w * h * chans);
     size_t rp = 0;
     for (int pass = 0; pass < (interlace ? 7 : 1); pass++) {
         const uint32_t x0 = interlace ? ax0[pass] : 0, y0 = interlace ? ay0[pass] : 0, dx = interlace ? adx[pass] : 1, dy = interlace ? ady[pass] : 1;

@@ -351,9 +351,11 @@ typedef struct {
 int crt_task_load(const char* config_json_path, crt_task* out);
 
 /* What the reference's texture decoder returns for a map_Kd file -- stbi_load(path, &x, &y, &comp, 0) of Loader.h:58: 8-bit
- * samples, row 0 = top, the file's own channel count.  Decodes PNG, BMP and TGA (csrc/crt_image.h; pinned against the
- * reference's vendored stb_image by tests/golden/stb_decode.json); JPEG, GIF, PSD, PIC, PNM and HDR files, which stb_image would
- * also read, return CRT_ERR_UNSUPPORTED.  out may be NULL (size query); cap = bytes available at out (x * y * comp needed). */
+ * samples, row 0 = top, the file's own channel count.  Decodes every format that decoder reads -- PNG (plain and Adam7), JPEG
+ * (baseline and progressive), BMP, TGA, GIF (first frame), PSD, Softimage PIC, binary PNM and Radiance HDR (csrc/crt_image.h,
+ * crt_png.h, crt_jpeg.h, crt_formats.h) -- with that decoder's own conventions, pinned sample for sample against the reference's
+ * vendored stb_image by tests/golden/stb_decode.json.  A file that is none of these, or damaged beyond what the reference's
+ * decoder accepts, returns CRT_ERR_UNSUPPORTED.  out may be NULL (size query); cap = bytes available at out (x * y * comp needed). */
 int crt_image_load(const char* path, int32_t* x, int32_t* y, int32_t* comp, uint8_t* out, uint64_t cap);
 
 /* stb-free PNG writer used by Render::save_frame_buffer's replacement (Render.cuh:489-493) */

@@ -7,7 +7,10 @@ The files cover what a map_Kd may point at (reference: include/Loader.h:55-105):
 1/2/4-bit palettes and greys, tRNS keys; BMP with 1/4/8-bit palettes, 16-bit 5-5-5 and 5-6-5 bit fields, 24 bit, 32 bit with and
 without alpha, top-down rows, V4/V5 headers, OS/2 header; TGA types 1/2/3/9/10/11, 15/16/24/32 bit, both origins, colour maps
 with 16/24/32-bit entries; Adam7-interlaced PNG at every depth; JPEG: baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey,
-CMYK, restart intervals, own Huffman and quantisation tables, sizes around the MCU boundaries, RGB component ids, Adobe transform 0."""
+CMYK, restart intervals, own Huffman and quantisation tables, sizes around the MCU boundaries, RGB component ids, Adobe transform 0;
+binary PNM (8 / 16 bit, header comments); GIF (87a / 89a, interlaced, transparency, local palette, background fill, table resets, a
+second frame that is not read); PSD (raw / PackBits, 8 / 16 bit, 1 - 5 channels, white-matte removal); Softimage PIC (raw, pure and
+mixed run-length packets); Radiance HDR (run-length and flat scanlines, both signatures)."""
 import json
 import os
 import struct
@@ -285,6 +288,240 @@ def main():
         J("jpg_411.jpg", photo, quality=85, subsampling="4:1:1")
     except Exception as e:  # PIL versions without that name
         print("no 4:1:1 fixture:", e, file=sys.stderr)
+    # ---- PNM (reference: stb_image.h:7491-7630) ----
+    open(P("pnm_p6.ppm"), "wb").write(b"P6\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+    open(P("pnm_p5.pgm"), "wb").write(b"P5 %d %d 255\n" % (w, h) + grey.tobytes())
+    open(P("pnm_p6_comments.ppm"), "wb").write(b"P6\r\n# made by hand\n# second comment\r\n%d\t%d # trailing\n\n255\n" % (w, h) + rgb.tobytes())
+    s16 = rng.integers(0, 65536, (h, w, 3), dtype=np.uint16)
+    open(P("pnm_p6_16.ppm"), "wb").write(b"P6\n%d %d\n65535\n" % (w, h) + s16.astype(">u2").tobytes())
+    open(P("pnm_p5_16_max1000.pgm"), "wb").write(b"P5\n%d %d\n1000\n" % (w, h) + (s16[:, :, 0] % 1001).astype(">u2").tobytes())
+    open(P("pnm_p5_max15.pgm"), "wb").write(b"P5\n%d %d\n15\n" % (w, h) + (grey & 15).tobytes())
+    # ---- GIF (reference: stb_image.h:6577-7080; only the first frame is read) ----
+
+    def gif_lzw(indices, min_code):
+        """Variable-width LZW as GIF packs it (least significant bit first), sub-blocks of at most 255 bytes."""
+        clear, eoi = 1 << min_code, (1 << min_code) + 1
+        out, acc, nbits = bytearray(), 0, 0
+        size = min_code + 1
+
+        def put(code):
+            nonlocal acc, nbits
+            acc |= code << nbits
+            nbits += size
+            while nbits >= 8:
+                out.append(acc & 255)
+                acc >>= 8
+                nbits -= 8
+        table, nxt = {}, eoi + 1
+        put(clear)
+        cur = ()
+        for v in indices:
+            v = int(v)
+            t = cur + (v,)
+            if len(t) == 1 or t in table:
+                cur = t
+                continue
+            put(cur[0] if len(cur) == 1 else table[cur])
+            table[t] = nxt
+            nxt += 1
+            if nxt > (1 << size) and size < 12:
+                size += 1
+            if nxt == 4096:
+                put(clear)
+                table, nxt, size = {}, eoi + 1, min_code + 1
+            cur = (v,)
+        if cur:
+            put(cur[0] if len(cur) == 1 else table[cur])
+        put(eoi)
+        if nbits:
+            out.append(acc & 255)
+        blocks = b"".join(bytes([len(out[i:i + 255])]) + bytes(out[i:i + 255]) for i in range(0, len(out), 255))
+        return bytes([min_code]) + blocks + b"\0"
+
+    def gif(path, sw, sh, frames, gpal=None, bg=0, version=b"89a", extra=b""):
+        """frames: list of dicts x, y, idx (2-D index array), optional lpal, transparent, interlace, dispose."""
+        def table(pal):
+            n = 2
+            while n < len(pal):
+                n *= 2
+            return n, b"".join(bytes(c) for c in pal) + b"\0\0\0" * (n - len(pal))
+        b = b"GIF" + version
+        if gpal:
+            n, t = table(gpal)
+            b += struct.pack("<HHBBB", sw, sh, 0x80 | (n.bit_length() - 2), bg, 0) + t
+        else:
+            b += struct.pack("<HHBBB", sw, sh, 0, bg, 0)
+        b += extra
+        for fr in frames:
+            idx = np.asarray(fr["idx"])
+            fh, fw = idx.shape
+            if "transparent" in fr or "dispose" in fr:
+                tr = fr.get("transparent")
+                b += b"\x21\xf9\x04" + bytes([(fr.get("dispose", 0) << 2) | (1 if tr is not None else 0)]) + struct.pack("<H", 7) + bytes([tr or 0]) + b"\0"
+            pal = fr.get("lpal")
+            flags = 0x40 if fr.get("interlace") else 0
+            lt = b""
+            ncol = len(pal or gpal)
+            if pal:
+                n, lt = table(pal)
+                flags |= 0x80 | (n.bit_length() - 2)
+            b += b"\x2c" + struct.pack("<HHHHB", fr.get("x", 0), fr.get("y", 0), fw, fh, flags) + lt
+            rows = list(range(fh))
+            if fr.get("interlace"):
+                rows = [r for (a, st) in ((0, 8), (4, 8), (2, 4), (1, 2)) for r in range(a, fh, st)]
+            mc = max(2, (max(ncol, 2) - 1).bit_length())
+            b += gif_lzw(idx[rows].reshape(-1), fr.get("min_code", mc))
+        open(path, "wb").write(b + b"\x3b")
+    pal64 = pal[:64]
+    i64 = rng.integers(0, 64, (h, w))
+    i64[2, 2:11] = i64[2, 2]
+    gif(P("gif_global_palette.gif"), w, h, [dict(idx=i64)], gpal=pal64)
+    gif(P("gif_87a.gif"), w, h, [dict(idx=i64)], gpal=pal64, version=b"87a")
+    gif(P("gif_interlaced.gif"), w, 19, [dict(idx=rng.integers(0, 64, (19, w)), interlace=True)], gpal=pal64)
+    gif(P("gif_transparent.gif"), w, h, [dict(idx=i64, transparent=int(i64[0, 0]))], gpal=pal64)
+    # a frame smaller than the screen, its own palette, a transparent index and a background index: what the frame leaves
+    # untouched gets the background entry
+    gif(P("gif_local_palette_bg.gif"), w, h, [dict(idx=rng.integers(0, 8, (4, 6)), x=3, y=2, lpal=pal[100:108], transparent=5)], gpal=pal64, bg=9)
+    gif(P("gif_bg_is_transparent.gif"), w, h, [dict(idx=rng.integers(0, 64, (3, 5)), x=1, y=1, transparent=9)], gpal=pal64, bg=9)
+    gif(P("gif_two_frames.gif"), w, h, [dict(idx=i64, dispose=2), dict(idx=rng.integers(0, 64, (h, w)), dispose=1)], gpal=pal64,
+        extra=b"\x21\xff\x0bNETSCAPE2.0\x03\x01\x00\x00\x00" + b"\x21\xfe\x05hello\x00")
+    gif(P("gif_two_colours.gif"), 19, 10, [dict(idx=rng.integers(0, 2, (10, 19)))], gpal=[(0, 0, 0), (255, 255, 255)])
+    gif(P("gif_noise_table_resets.gif"), 96, 96, [dict(idx=rng.integers(0, 256, (96, 96)))], gpal=[tuple(int(v) for v in rng.integers(0, 256, 3)) for _ in range(256)])
+    gif(P("gif_smooth_long_strings.gif"), 80, 60, [dict(idx=(np.mgrid[0:60, 0:80][1] // 9 + np.mgrid[0:60, 0:80][0] // 17) % 16, interlace=True)], gpal=pal[:16])
+    # ---- PSD (reference: stb_image.h:6078-6330) ----
+
+    def packbits(row):
+        out, i = bytearray(), 0
+        while i < len(row):
+            run = 1
+            while i + run < len(row) and run < 128 and row[i + run] == row[i]:
+                run += 1
+            if run >= 3:
+                out += bytes([257 - run, row[i]])
+                i += run
+                continue
+            j = i
+            while j < len(row) and j - i < 128 and not (j + 2 < len(row) and row[j] == row[j + 1] == row[j + 2]):
+                j += 1
+            out += bytes([j - i - 1]) + bytes(row[i:j])
+            i = j
+        return bytes(out)
+
+    def psd(path, planes, depth=8, rle=False, resources=b""):
+        ch, hh, ww = planes.shape
+        b = b"8BPS" + struct.pack(">H6xHIIHH", 1, ch, hh, ww, depth, 3) + struct.pack(">I", 0) + struct.pack(">I", len(resources)) + resources + struct.pack(">I", 0)
+        if not rle:
+            b += struct.pack(">H", 0) + (planes.astype(">u2").tobytes() if depth == 16 else planes.astype(np.uint8).tobytes())
+        else:
+            rows = [packbits(bytes(planes[c, y].astype(np.uint8))) for c in range(ch) for y in range(hh)]
+            b += struct.pack(">H", 1) + b"".join(struct.pack(">H", len(r)) for r in rows) + b"".join(rows)
+        open(path, "wb").write(b)
+    planes = np.stack([rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 2]])
+    a_mixed = alpha.copy()
+    a_mixed[0, :4] = 0
+    a_mixed[1, :4] = 255
+    a_mixed[3, 2:9] = a_mixed[3, 2]
+    psd(P("psd_rgb8_raw.psd"), planes, resources=b"8BIM\x03\xed\0\0\0\0\0\x04abcd")
+    psd(P("psd_rgb8_rle.psd"), planes, rle=True)
+    psd(P("psd_rgba8_raw_matte.psd"), np.concatenate([planes, a_mixed[None]]))
+    psd(P("psd_rgba8_rle_matte.psd"), np.concatenate([planes, a_mixed[None]]), rle=True)
+    psd(P("psd_rgb16_raw.psd"), np.moveaxis(s16, 2, 0), depth=16)
+    psd(P("psd_rgba16_raw.psd"), np.concatenate([np.moveaxis(s16, 2, 0), (a_mixed.astype(np.uint16) * 257)[None]]), depth=16)
+    psd(P("psd_one_channel.psd"), grey[None])
+    psd(P("psd_five_channels_rle.psd"), np.concatenate([planes, a_mixed[None], grey[None]]), rle=True)
+    # ---- Softimage PIC (reference: stb_image.h:6343-6545) ----
+
+    def pic(path, img4, packets):
+        """img4: (h, w, 4) RGBA; packets: list of (type, channel mask)."""
+        hh, ww, _ = img4.shape
+        b = b"\x53\x80\xf6\x34" + struct.pack(">f", 3.71) + b"fixture".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", ww, hh, 1.0, 3, 0)
+        for k, (typ, mask) in enumerate(packets):
+            b += bytes([1 if k + 1 < len(packets) else 0, 8, typ, mask])
+        for y in range(hh):
+            for typ, mask in packets:
+                chans = [c for c in range(4) if mask & (0x80 >> c)]
+                px = [bytes(int(img4[y, x, c]) for c in chans) for x in range(ww)]
+                if typ == 0:
+                    b += b"".join(px)
+                    continue
+                x = 0
+                while x < ww:
+                    run = 1
+                    while x + run < ww and px[x + run] == px[x] and run < (255 if typ == 1 else 300):
+                        run += 1
+                    if typ == 1:
+                        b += bytes([run]) + px[x]
+                        x += run
+                    elif run >= 2:
+                        b += (bytes([127 + run]) if run <= 128 else b"\x80" + struct.pack(">H", run)) + px[x]
+                        x += run
+                    else:
+                        j = x
+                        while j < ww and j - x < 128 and not (j + 1 < ww and px[j] == px[j + 1]):
+                            j += 1
+                        b += bytes([j - x - 1]) + b"".join(px[x:j])
+                        x = j
+        open(path, "wb").write(b)
+    rgba = np.dstack([rgb, a_mixed])
+    wide = np.zeros((5, 300, 4), dtype=np.uint8)
+    wide[:, :, :3] = (np.arange(300)[None, :, None] // 150 * 200 + np.arange(5)[:, None, None] * 7) % 256   # runs longer than 128
+    wide[:, :, 3] = 255
+    wide[2, 100:103, 1] = (9, 8, 7)
+    pic(P("pic_rgb_raw.pic"), rgba, [(0, 0xE0)])
+    pic(P("pic_rgb_pure_rle.pic"), rgba, [(1, 0xE0)])
+    pic(P("pic_rgba_mixed_rle.pic"), rgba, [(2, 0xE0), (1, 0x10)])
+    pic(P("pic_channels_in_separate_packets.pic"), rgba, [(2, 0x80), (0, 0x40), (1, 0x20), (2, 0x10)])
+    pic(P("pic_long_runs.pic"), wide, [(2, 0xE0)])
+    # ---- Radiance HDR (reference: stb_image.h:7084-7290, 1883-1910) ----
+
+    def rgbe(f):
+        """float RGB (h, w, 3) -> RGBE bytes (h, w, 4)"""
+        m = f.max(axis=2)
+        e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0)
+        sc = np.where(m > 1e-32, 256.0 / np.exp2(e), 0)
+        out = np.zeros(f.shape[:2] + (4,), dtype=np.uint8)
+        out[:, :, :3] = np.clip(f * sc[:, :, None], 0, 255).astype(np.uint8)
+        out[:, :, 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+        return out
+
+    def hdr(path, px, rle=True, magic=b"#?RADIANCE", rle_rows=None):
+        hh, ww, _ = px.shape
+        b = magic + b"\n# fixture\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (hh, ww)
+        for y in range(hh):
+            if not rle or (rle_rows is not None and y not in rle_rows):
+                b += px[y].tobytes()
+                continue
+            b += bytes([2, 2, ww >> 8, ww & 255])
+            for k in range(4):
+                row, x = px[y, :, k], 0
+                while x < ww:
+                    run = 1
+                    while x + run < ww and run < 127 and row[x + run] == row[x]:
+                        run += 1
+                    if run >= 3:
+                        b += bytes([128 + run, int(row[x])])
+                        x += run
+                    else:
+                        j = x
+                        while j < ww and j - x < 128 and not (j + 2 < ww and row[j] == row[j + 1] == row[j + 2]):
+                            j += 1
+                        b += bytes([j - x]) + bytes(row[x:j])
+                        x = j
+        open(path, "wb").write(b)
+    yy, xx = np.mgrid[0:11, 0:23]
+    lum = np.stack([np.exp2((xx - 11) / 2.0) * (1 + yy / 5.0), 0.02 + xx * yy / 40.0, np.where((xx + yy) % 5 == 0, 0.0, 3.0 / (1 + yy))], axis=2)
+    lum[4, 3:12] = lum[4, 3]
+    lum[7, :, :] = 0.0
+    e = rgbe(lum)
+    hdr(P("hdr_rle.hdr"), e)
+    hdr(P("hdr_rgbe_magic.hdr"), e, magic=b"#?RGBE")
+    hdr(P("hdr_flat_narrow.hdr"), e[:, :7], rle=False)                 # narrower than 8: never run-length coded
+    hdr(P("hdr_flat_wide.hdr"), e, rle=False)                          # flat data where run-length scanlines may stand
+    hdr(P("hdr_flat_after_rle_rows.hdr"), e, rle_rows={0, 1})          # the third scanline is flat: the decoder restarts at pixel 1
+    noise = rng.integers(0, 256, (9, 16, 4), dtype=np.uint8)
+    noise[:, :, 3] = rng.integers(120, 136, (9, 16))
+    noise[0, 0] = (200, 10, 10, 128)
+    hdr(P("hdr_noise_rle.hdr"), noise)
     # ---- what the reference's decoder says ----
     files = sorted(os.listdir(OUT))
     import hashlib
@@ -293,14 +530,15 @@ def main():
         out = subprocess.check_output([PROBE] + [os.path.join(OUT, f) for f in files], env=dict(os.environ, STB_PROBE_DUMP=dump))
         gold = json.loads(out)
         # the JPEG files in full: no second decoder returns stb_image's samples for them (inverse DCT, upsampling and colour
-        # arithmetic are the decoder's own), so the oracle of the tests is fed from here -- keyed by the SHA-1 of the file
+        # arithmetic are the decoder's own), so the oracle of the tests is fed from here -- keyed by the SHA-1 of the file; the GIF,
+        # PSD, PIC, PNM and HDR files too (first-frame / matte / byte-order / tone-mapping conventions of that decoder)
         full = {}
         for f in files:
-            if f.endswith(".jpg") and "error" not in gold[f]:
+            if f.endswith((".jpg", ".gif", ".psd", ".pic", ".ppm", ".pgm", ".hdr")) and "error" not in gold[f]:
                 g = gold[f]
                 a = np.fromfile(os.path.join(dump, f + ".raw"), dtype=np.uint8).reshape(g["y"], g["x"], g["comp"])
                 full[hashlib.sha1(open(os.path.join(OUT, f), "rb").read()).hexdigest()] = a
-        np.savez_compressed(os.path.join(HERE, "stb_jpeg_samples.npz"), **full)
+        np.savez_compressed(os.path.join(HERE, "stb_samples.npz"), **full)
     bad = {k: v for k, v in gold.items() if "error" in v}
     if bad:
         print("stb_image rejects:", bad, file=sys.stderr)

@@ -111,16 +111,17 @@ def stb_like_decode(path):
     An independent decoder: the product has its own PNG reader (csrc/crt_png.h)."""
     from PIL import Image
     with open(path, "rb") as f:
-        head = f.read(2)
-    if head == b"\xff\xd8":
+        head = f.read(12)
+    if head[:2] == b"\xff\xd8" or head[:4] in (b"GIF8", b"8BPS", b"\x53\x80\xf6\x34") or head[:2] in (b"P5", b"P6") or head[:2] == b"#?":
         # JPEG: the inverse DCT, the chroma upsampling and the colour arithmetic are a decoder's own choice, so no second decoder returns
-        # the reference's samples.  The oracle is fed with what the REFERENCE's stb_image returned for the file (tests/golden/
-        # stb_jpeg_samples.npz, written by tests/golden/make_texture_golden.py from oracle/_ref/stb_probe, keyed by the file's SHA-1).
+        # the reference's samples; GIF / PSD / PIC / PNM / HDR: first frame and background, matte removal, byte order and tone mapping are
+        # that decoder's conventions.  The oracle is fed with what the REFERENCE's stb_image returned for the file (tests/golden/
+        # stb_samples.npz, written by tests/golden/make_texture_golden.py from oracle/_ref/stb_probe, keyed by the file's SHA-1).
         import hashlib
         key = hashlib.sha1(open(path, "rb").read()).hexdigest()
-        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stb_jpeg_samples.npz"))
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stb_samples.npz"))
         if key not in z.files:
-            raise RuntimeError("no golden stb_image samples for the JPEG file %s (tests/golden/make_texture_golden.py)" % path)
+            raise RuntimeError("no golden stb_image samples for the file %s (tests/golden/make_texture_golden.py)" % path)
         a = np.ascontiguousarray(z[key], dtype=np.uint8)
         return a.shape[1], a.shape[0], a.shape[2], a
     img = Image.open(path)

@@ -102,14 +102,14 @@ def test_textured_materials_match_oracle(tmp_path, kind, w, h):
     assert (x, y) == (w, h) and comp >= 1
 
 
-def test_png_reader_rejects_what_it_does_not_support(tmp_path):
+def test_a_texture_that_cannot_be_decoded_fails_the_scene(tmp_path):
     obj, mtl = _write_scene(str(tmp_path), "rgb", 8, 8)
-    with open(os.path.join(mtl, "tex.png"), "wb") as f:   # a GIF signature: stb_image would decode it, this build says unsupported
+    with open(os.path.join(mtl, "tex.png"), "wb") as f:   # a GIF signature and nothing behind it (the name of the file does not matter)
         f.write(b"GIF89a" + b"\0" * 64)
     s = crt.Scene(8, 8)
     with pytest.raises(crt.CrtError) as e:
         s.add_obj(obj, mtl)
-    assert "GIF" in str(e.value) and "PNG" in str(e.value)
+    assert "GIF" in str(e.value) and "tex.png" in str(e.value)
     os.remove(os.path.join(mtl, "tex.png"))
     with pytest.raises(crt.CrtError):
         crt.Scene(8, 8).add_obj(obj, mtl)
@@ -161,11 +161,12 @@ def _fnv1a64(a):
 def test_decoders_match_the_references_own_stb_image():
     """tests/golden/stb_decode.json = what the reference's vendored stb_image.h returns for the fixture files (x, y, comp and
     every sample, via oracle/ref_probe/stb_probe.c): the product's decoders (PNG plain and Adam7-interlaced, JPEG baseline and
-    progressive, BMP, TGA) must return exactly that, and so must the feed of the oracle (PIL for the PNG files: 16 -> 8-bit
-    reduction, palette / tRNS expansion, channel counts; the golden samples themselves for the JPEG files)."""
+    progressive, BMP, TGA, GIF, PSD, PIC, PNM, HDR -- every format that decoder reads) must return exactly that, and so must the
+    feed of the oracle (PIL for the PNG files: 16 -> 8-bit reduction, palette / tRNS expansion, channel counts; the golden samples
+    themselves for the JPEG, GIF, PSD, PIC, PNM and HDR files)."""
     import json
     gold = json.load(open(os.path.join(util.ROOT, "tests", "golden", "stb_decode.json")))["files"]
-    assert len(gold) >= 80
+    assert len(gold) >= 115
     kinds = set()
     n_jpg = n_adam7 = 0
     for name, g in sorted(gold.items()):
@@ -175,12 +176,12 @@ def test_decoders_match_the_references_own_stb_image():
         assert _fnv1a64(a) == g["fnv1a64"], name
         assert list(a.reshape(-1)[:24]) == g["head"], name
         kinds.add(name.split("_")[0])
-        if name.endswith((".png", ".jpg")):
+        if not name.endswith((".bmp", ".tga")):
             px, py, pc, pa = O.stb_like_decode(path)
             assert (px, py, pc) == (g["x"], g["y"], g["comp"]) and _fnv1a64(pa) == g["fnv1a64"], name
         n_jpg += name.endswith(".jpg")
         n_adam7 += "adam7" in name
-    assert kinds == {"png", "bmp", "tga", "jpg"} and n_jpg >= 30 and n_adam7 >= 8
+    assert kinds == {"png", "bmp", "tga", "jpg", "gif", "psd", "pic", "pnm", "hdr"} and n_jpg >= 30 and n_adam7 >= 8
 
 
 def _use_fixture_texture(d, fixture):
@@ -273,18 +274,75 @@ def test_bmp_and_tga_textures_feed_the_materials(tmp_path, ext, fmt):
     assert len(np.unique(mats["kd"][t1["material"]].round(6), axis=0)) > 10
 
 
-def test_formats_outside_this_build_are_named(tmp_path):
-    """stb_image would also read GIF, PSD, PIC, PNM and HDR; this build says which format it met and that it is unsupported."""
-    for magic, name in ((b"GIF89a", "GIF"), (b"8BPS", "PSD"), (b"P6\n2 2\n255\n", "PNM"), (b"#?RADIANCE\n", "Radiance HDR")):
+def test_files_that_are_no_image_are_rejected(tmp_path):
+    """What the reference's decoder calls "unknown image type" (and a GIF signature of a version that does not exist, which it passes on
+    to its other format tests) is CRT_ERR_UNSUPPORTED here; a missing file is CRT_ERR_IO."""
+    for content in (b"GIF88a" + b"\x01" * 64, b"hello, world\n" * 8, b"P7\n2 2\n255\n" + b"\x07" * 12, b"#?RADIANCE" + b"\xff" * 40):
         p = str(tmp_path / "t.bin")
         with open(p, "wb") as f:
-            f.write(magic + b"\0" * 64)
+            f.write(content)
         with pytest.raises(crt.CrtError) as e:
             crt.image_load(p)
-        assert e.value.status == -4 and name in str(e.value)
+        assert e.value.status == -4, content[:8]
     with pytest.raises(crt.CrtError) as e:
         crt.image_load(str(tmp_path / "missing.png"))
     assert e.value.status == -5
+
+
+@pytest.mark.parametrize("fixture", ["gif_local_palette_bg.gif", "psd_rgba8_rle_matte.psd", "pic_rgba_mixed_rle.pic", "pnm_p6_16.ppm", "hdr_rle.hdr"])
+def test_the_rarer_formats_feed_the_materials(tmp_path, fixture):
+    """map_Kd pointing at a GIF / PSD / PIC / PNM / HDR file: per-triangle kd as the oracle computes it from the samples the REFERENCE's
+    stb_image returns for that file (golden data), bit for bit."""
+    d = str(tmp_path)
+    obj, mtl = _write_scene(d, "rgb", 16, 16)
+    tex = _use_fixture_texture(d, fixture)
+    x, y, comp, mine = crt.image_load(tex)
+    px, py, pc, ref = O.stb_like_decode(tex)
+    assert (x, y, comp) == (px, py, pc) and np.array_equal(mine, ref)
+    scene = crt.Scene(32, 24)
+    scene.add_obj(obj, mtl)
+    scene.set_BVH(2)
+    osc = O.OracleScene([(obj, mtl)], 2)
+    t1, t2 = scene.triangles(), osc.tris()
+    mats = scene.materials()
+    for k in ("kd", "ke", "ns"):
+        assert np.array_equal(util.bits(mats[k][t1["material"]]), util.bits(t2[k])), k
+    assert len(np.unique(mats["kd"][t1["material"]].round(6), axis=0)) > 4
+
+
+@pytest.mark.parametrize("name", ["gif_interlaced.gif", "gif_local_palette_bg.gif", "gif_noise_table_resets.gif", "psd_rgba8_rle_matte.psd", "psd_rgb16_raw.psd",
+                                  "pic_rgba_mixed_rle.pic", "pic_long_runs.pic", "pnm_p6_comments.ppm", "pnm_p5_16_max1000.pgm", "hdr_rle.hdr",
+                                  "hdr_flat_after_rle_rows.hdr"])
+def test_damaged_files_of_the_rarer_formats_are_decoded_or_rejected(tmp_path, name):
+    """Random damage to valid GIF / PSD / PIC / PNM / HDR files: an image or an error, never an out-of-bounds access or an endless loop."""
+    import random
+    random.seed(17)
+    orig = open(os.path.join(util.ROOT, "tests", "golden", "textures", name), "rb").read()
+    p = str(tmp_path / name)
+    ok = bad = 0
+    for it in range(200):
+        b = bytearray(orig)
+        mode = it % 4
+        if mode == 0:
+            for _ in range(random.randint(1, 4)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif mode == 1:
+            b = b[:random.randrange(8, len(b))]
+        elif mode == 2:
+            i = random.randrange(6, len(b))
+            b[i:i] = bytes(random.randrange(256) for _ in range(random.randint(1, 16)))
+        else:   # header bytes
+            i = random.randrange(4, min(len(b) - 2, 120))
+            b[i:i + 2] = random.getrandbits(16).to_bytes(2, "big")
+        with open(p, "wb") as f:
+            f.write(bytes(b))
+        try:
+            x, y, comp, a = crt.image_load(p)
+            assert a.size == x * y * comp and 1 <= comp <= 4
+            ok += 1
+        except crt.CrtError:
+            bad += 1
+    assert ok + bad == 200 and ok > 10 and bad > 5, (ok, bad)
 
 
 @pytest.mark.parametrize("name", ["bmp_8_palette.bmp", "bmp_16_565.bmp", "bmp_32_v5_alpha_mask.bmp", "tga_24_rle.tga", "tga_cmap24_rle.tga", "tga_cmap32_idx16.tga"])
