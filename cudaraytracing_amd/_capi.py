@@ -15,6 +15,7 @@ FLAG_STATS = 1
 FLAG_TILED_OUTPUT = 2
 FLAG_FORCE_EXACT = 4
 FLAG_TRACE_ALL = 8
+FLAG_BOUNDED_RADIANCE = 16
 GATHER_AUTO, GATHER_RCCL, GATHER_COPY = 0, 1, 2
 INTERSECT_RAW_DIRECTIONS, INTERSECT_FORCE_EXACT, INTERSECT_VISIBILITY = 0x100, 0x200, 0x400
 TILE = 8
@@ -118,7 +119,7 @@ ABI_VERSION = 3  # include/crt.h: CRT_ABI_VERSION
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
-           "crt_scene_accel_info", "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
+           "crt_scene_accel_info", "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_radiance_storage", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
            "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_set_bvh_device", "crt_host_scene_desc", "crt_host_scene_num_objects",
@@ -157,6 +158,7 @@ def lib():
     L.crt_render_range_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.crt_last_launch_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+    L.crt_radiance_storage.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.crt_preview.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.crt_preview_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.crt_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]

@@ -243,6 +243,13 @@ class Render:
         capi.check(capi.lib().crt_last_launch_ms(self._handle("last_launch_ms"), C.byref(ms), C.byref(n)), "crt_last_launch_ms")
         return float(ms.value), int(n.value)
 
+    def radiance_storage(self):
+        """(bytes, ring samples) of the per-path radiance storage of the last render on this handle (crt_radiance_storage): one value per
+        path of a chunk, or -- FLAG_BOUNDED_RADIANCE -- a ring of that many samples."""
+        b, r = C.c_uint64(), C.c_uint32()
+        capi.check(capi.lib().crt_radiance_storage(self._handle("radiance_storage"), C.byref(b), C.byref(r)), "crt_radiance_storage")
+        return int(b.value), int(r.value)
+
     def preview(self, want_mean=False, width=None, height=None):
         """Displayable frame of the progressive render in flight (crt_preview): returns (rgb (H, W, 3), mean or None, samples done).
         Reads the accumulator only -- the final frame does not depend on previews."""

@@ -108,6 +108,20 @@ struct LParams {
                                // (k_order_items): [ITEM_SHARDS][order_window]
     uint32_t order_window;
     FastDiv items_per_shard_div;
+    // ---- in-order commit through a ring of samples (bounded radiance storage, see commit_ring below); ring_mask == 0: off ----
+    uint32_t ring_mask;       // ring samples - 1 (a power of two)
+    uint32_t spsh;            // pixel slots per cursor shard (a multiple of 64: whole tiles)
+    FastDiv spsh_div;
+    uint32_t ring_shards;     // cursor shards of a ring launch (a power of two >= ITEM_SHARDS: a shard's commits are a serial chain,
+                              // so there are more and smaller ones than without the ring)
+    uint32_t ring_stride;     // slots per ring sample (= ring_shards * spsh)
+    uint32_t n_samples;       // samples of this launch
+    uint32_t tail_first;      // in-shard position where the ordered tail window begins (its items may belong to any later sample)
+    float spp_f;              // (float)spp
+    uint32_t ring_pad_;
+    unsigned int* ring_done;  // [ring_shards][ring samples]: finished work items of (shard, sample mod ring)
+    unsigned int* ring_state; // [ring_shards * ITEM_STRIDE]: word 0 = committed samples | busy << 31, word 1 = valid pixel slots of the shard
+    float* accum;             // 3 planes of nslots: sum of L_k / spp over the committed samples (Render.cuh:348)
 };
 
 struct TParams {
@@ -177,6 +191,36 @@ __device__ __forceinline__ uint32_t grab_item(const unsigned int* /*unused*/, un
     return item;
 }
 
+// The same for a commit-ring launch (P.ring_shards cursor shards): the cursors of as many shards as there are lanes asking are looked
+// at in one round trip, not one after the other -- at the end of a launch every ray slot walks all shards once.
+__device__ __forceinline__ uint32_t grab_item_ring(unsigned int* item_next, const uint32_t per, const uint32_t n_shards, const uint32_t home)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t item = ITEM_NONE;
+    uint32_t t = 0;
+    for (;;) {
+        // the lanes asking, numbered 0 .. n - 1, each look at one shard: home + t + number
+        const unsigned long long mask = __ballot(1);
+        const uint32_t n = (uint32_t)__popcll(mask), rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (t >= n_shards) break; // (t is the same in every lane that is still here)
+        const uint32_t look = (home + t + rank) & (n_shards - 1u);
+        const bool has = t + rank < n_shards && __hip_atomic_load((CRT_GAS unsigned int*)(item_next + look * ITEM_STRIDE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < per;
+        const unsigned long long found = __ballot(has);
+        if (!found) { t += n; continue; }
+        // the first shard in walking order that has items: the lane with the lowest number among `found`
+        const int src = __ffsll((long long)found) - 1;
+        const uint32_t sh = (uint32_t)__builtin_amdgcn_readlane((int)look, src);
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = __hip_atomic_fetch_add((CRT_GAS unsigned int*)(item_next + sh * ITEM_STRIDE), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+        const unsigned long long idx = (unsigned long long)base + rank;
+        if (idx < per) { item = sh * per + (uint32_t)idx; break; }
+        // (the shard ran dry under this wave's hands: those without an item look again, from the same place)
+    }
+    return item;
+}
+
 // ---------------------------------------------------------------- logic ----
 struct PathCounters {
     uint32_t rays, shadow, probe, paths;
@@ -190,14 +234,131 @@ struct Lane {
     uint32_t pixel_index, k;
 };
 
+template <bool RING = false>
 __device__ __forceinline__ void decode_item(const LParams& P, uint32_t item, uint32_t& pixel_index, uint32_t& k, bool& valid,
                                             uint32_t& pi, uint32_t& pj)
 {
-    uint32_t s = fast_div(item, P.nslots_div.m, P.nslots_div.sh);
-    uint32_t slot = item - s * P.nslots;
+    uint32_t s, slot;
+    if (RING) { // cursor shard = a range of pixel slots, sample-major inside it (commit ring)
+        const uint32_t sh = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh), c = item - sh * P.items_per_shard;
+        s = fast_div(c, P.spsh_div.m, P.spsh_div.sh);
+        slot = sh * P.spsh + (c - s * P.spsh);
+    } else {
+        s = fast_div(item, P.nslots_div.m, P.nslots_div.sh);
+        slot = item - s * P.nslots;
+    }
     k = P.sample_begin + s;
-    valid = slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.tiles_x_div, P.width, P.height, pi, pj);
+    valid = (!RING || slot < P.nslots) && slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.tiles_x_div, P.width, P.height, pi, pj);
     pixel_index = pj * P.width + pi; // Render.cuh:336
+}
+
+// ---- commit ring: the frame's sum c += L_k / spp in sample order (Render.cuh:348) INSIDE the launch, with storage for a window of
+// samples instead of one radiance per work item.  The cursor shards are ranges of pixel slots; every shard walks its samples in order,
+// so the work items in flight lie within a few samples of one another.  L[(sample mod ring)][slot] holds a finished path's radiance;
+// ring_done counts the finished items of (shard, sample); the wave whose count completes a sample commits it -- and the samples
+// after it that are complete -- if it is the next one of its shard, else leaves it to the wave that commits the one before (one word
+// per shard: committed samples | busy).  A work item of sample s is started only while s < committed + ring samples, so a slot of the
+// ring is never overwritten before it has been read; a ray slot that is handed an item beyond that holds it (stage ST_WAIT) and asks
+// again on its next turn.  Nothing waits on a wave that is not resident: what a shard's next commit needs are items already handed
+// out, and the waves holding them go on by themselves.  Visibility across the XCDs' L2 caches: the ring, the accumulator and the
+// protocol words live in uncached device memory (hipDeviceMallocUncached) AND are accessed with agent-scope atomics only (plain
+// accesses to uncached memory were seen to return stale accumulator values); a wave orders its accesses with s_waitcnt.
+#define ST_WAIT 6 /* the ray slot holds a work item it may not start yet */
+typedef CRT_GAS unsigned int* ring_word_ptr;
+__device__ __forceinline__ unsigned int ring_load(const unsigned int* p) { return __hip_atomic_load((ring_word_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ring_loadf(const float* p) { return __uint_as_float(__hip_atomic_load((ring_word_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void ring_storef(float* p, const float v) { __hip_atomic_store((ring_word_ptr)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ring_wait_mem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define RING_BUSY 0x80000000u
+
+// May the work item be started?  (in-shard position c: items of the ordered tail window stand for the last sample)
+__device__ __forceinline__ bool ring_gate_open(const LParams& P, const uint32_t item, const uint32_t home, const uint32_t home_word)
+{
+    const uint32_t sh = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh), c = item - sh * P.items_per_shard;
+    const uint32_t need = c >= P.tail_first ? P.n_samples - 1u : fast_div(c, P.spsh_div.m, P.spsh_div.sh);
+    // (the word of the wave's home shard was fetched ahead, with the cursor: an older value only says "wait" where "go" was possible)
+    const uint32_t committed = (sh == home ? home_word : ring_load(P.ring_state + sh * ITEM_STRIDE)) & ~RING_BUSY;
+    return need - committed <= P.ring_mask; // need < committed + ring samples (need >= committed: its own sample is not committed yet)
+}
+
+// The wave (all 64 lanes) commits what is complete and next in shard sh.
+__device__ __forceinline__ void ring_commit(const LParams& P, const uint32_t sh)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned int* word = P.ring_state + sh * ITEM_STRIDE;
+    const uint32_t n_valid = ring_load(word + 1);
+    for (;;) {
+        const uint32_t w = ring_load(word);
+        if (w & RING_BUSY) return;           // the wave that holds the shard looks again when it is done
+        if (w >= P.n_samples) return;        // every sample of the launch is committed
+        unsigned int* done = P.ring_done + sh * (P.ring_mask + 1u) + (w & P.ring_mask);
+        if (ring_load(done) != n_valid) return; // the next sample is not complete
+        unsigned int got = 0;
+        if (lane == 0) {
+            unsigned int expect = w;
+            got = __hip_atomic_compare_exchange_strong((ring_word_ptr)word, &expect, w | RING_BUSY, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        }
+        if (!__builtin_amdgcn_readfirstlane((int)got)) continue;
+        // ---- sample w of the shard: c += L / spp for every pixel slot (Render.cuh:348); four slots per lane and round trip ----
+        const float4* Lr = P.L + (size_t)(w & P.ring_mask) * P.ring_stride + (size_t)sh * P.spsh;
+        const bool from_zero = P.sample_begin + w == 0u;
+        for (uint32_t i0 = (uint32_t)lane; i0 < P.spsh; i0 += 256u) {
+            float l[4][3], c[4][3];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = i0 + 64u * (uint32_t)u, slot = sh * P.spsh + i;
+                uint32_t pi, pj;
+                ok[u] = i < P.spsh && slot < P.nslots && slot_to_pixel(slot, P.rank, P.world, P.n_tiles, P.tiles_x, P.tiles_x_div, P.width, P.height, pi, pj);
+                l[u][0] = l[u][1] = l[u][2] = 0.0f; c[u][0] = c[u][1] = c[u][2] = 0.0f;
+                if (ok[u]) {
+                    l[u][0] = ring_loadf(&Lr[i].x); l[u][1] = ring_loadf(&Lr[i].y); l[u][2] = ring_loadf(&Lr[i].z);
+                    if (!from_zero) { c[u][0] = ring_loadf(P.accum + slot); c[u][1] = ring_loadf(P.accum + P.nslots + slot); c[u][2] = ring_loadf(P.accum + 2ull * P.nslots + slot); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t slot = sh * P.spsh + i0 + 64u * (uint32_t)u;
+                if (ok[u]) {
+                    ring_storef(P.accum + slot, c[u][0] + l[u][0] / P.spp_f);
+                    ring_storef(P.accum + P.nslots + slot, c[u][1] + l[u][1] / P.spp_f);
+                    ring_storef(P.accum + 2ull * P.nslots + slot, c[u][2] + l[u][2] / P.spp_f);
+                }
+            }
+        }
+        if (lane == 0) __hip_atomic_store((ring_word_ptr)done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for sample w + ring samples
+        ring_wait_mem(); // accumulator and counter are written before the shard is handed on
+        unsigned int prev = 0;
+        if (lane == 0) prev = __hip_atomic_exchange((ring_word_ptr)word, w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__builtin_amdgcn_readfirstlane((int)prev); // (returned: the hand-over is performed before the next look at the counters)
+    }
+}
+
+// The lanes with fin_key != ~0u have written the radiance of a finished work item of (shard, ring slot) = (fin_key >> 16, fin_key & 0xffff):
+// one atomic per distinct key, and the commit of whatever that completes.  All 64 lanes.
+__device__ __forceinline__ void ring_publish(const LParams& P, const uint32_t fin_key)
+{
+    unsigned long long todo = __ballot(fin_key != ~0u);
+    if (!todo) return;
+    // (the pixel count of the first key's shard -- nearly always the only key -- is fetched under the same wait as the stores)
+    const uint32_t first_sh = (uint32_t)__builtin_amdgcn_readlane((int)fin_key, __ffsll((long long)todo) - 1) >> 16;
+    const uint32_t first_valid = ring_load(P.ring_state + first_sh * ITEM_STRIDE + 1);
+    ring_wait_mem(); // the radiance is in memory before it is counted
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)fin_key, leader);
+        const unsigned long long m = __ballot(fin_key == key);
+        const uint32_t sh = key >> 16, n = (uint32_t)__popcll(m);
+        unsigned int old = 0;
+        if (lane == leader) old = __hip_atomic_fetch_add((ring_word_ptr)(P.ring_done + sh * (P.ring_mask + 1u) + (key & 0xffffu)), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned int)__builtin_amdgcn_readlane((int)old, leader);
+        // (told to the compiler as next to never: the loops of the commit would otherwise weigh in its register allocation like the
+        // traversal loops and push their scalars out into vector-register lanes)
+        if (__builtin_expect_with_probability(old + n == (sh == first_sh ? first_valid : ring_load(P.ring_state + sh * ITEM_STRIDE + 1)), 0, 0.999999))
+            ring_commit(P, sh);
+        todo &= ~m;
+    }
 }
 
 #define LOGIC_TABLE_MAX 64 /* materials / lights kept in LDS when they fit */
@@ -262,12 +423,13 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
 // needed (two multiply-shift divisions and the tile arithmetic).  Against keeping (pixel, sample, item) as 16 B, measured on C2 with
 // one --pmc pass per counter: memory-side traffic 431.7 -> 382.7 GB per launch, L2 miss rate 0.495 -> 0.467, vector instructions
 // + 1.2 %, frame 96.7 -> 95.5 ms (profiles/r03_traffic_id_plane.txt).  (The wavefront pipeline keeps the 16-byte entries.)
+template <bool RING = false>
 __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
 {
     const uint32_t item = gld((const uint32_t*)P.pool.id + g);
     uint32_t pixel_index, k, pi, pj;
     bool valid;
-    decode_item(P, item, pixel_index, k, valid, pi, pj);
+    decode_item<RING>(P, item, pixel_index, k, valid, pi, pj);
     return make_uint4(pixel_index, k, item, 0u);
 }
 __device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t item)
@@ -944,6 +1106,8 @@ struct MParams {
 #define PH3_LB 3
 #define PH3_LC 4
 #define PH3_N 5
+#define PH3_WAIT 5 /* commit ring: ray slots that hold a work item they may not start yet -- a ring like the others, but outside PH3_N:
+                      only the LC phase feeds it and only the LC phase looks at it */
 #define PH3_NONE 7
 #define ST_FIN 5   /* path complete, backward recursion pending (q bit 0: the deepest vertex is an emitter) */
 #define ST_NEED 6  /* vertex entered with zero next-event samples: straight to roulette */
@@ -994,7 +1158,8 @@ struct Pool3LdsT {
     int node[POOL3_P];           // current node ref
     stk_t stk[LV][POOL3_P];      // traversal stack (node refs); deeper levels spill to global memory
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
-    uint8_t ring[PH3_N][POOL3_QCAP];
+    uint8_t ring[PH3_N + 1][POOL3_QCAP];
+    uint32_t waitq;              // ring PH3_WAIT: entries | head << 8 | tail << 16 (kept here, not in scalar registers: only the LC phase uses it)
 };
 typedef Pool3LdsT<false> Pool3Lds;
 static_assert(sizeof(Pool3LdsT<true>) == sizeof(Pool3Lds), "16-bit stack entries: twice the levels in the same bytes");
@@ -1007,7 +1172,7 @@ struct MParams3 {
     int32_t dbg_loads, dbg_valu; // unused by the kernel; tools/bbprof passes the address of its counter buffer in these two dwords
 };
 
-static_assert(offsetof(MParams3, dbg_loads) == 588 && offsetof(MParams3, dbg_valu) == 592, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
+static_assert(offsetof(MParams3, dbg_loads) == 652 && offsetof(MParams3, dbg_valu) == 656, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
 
 struct NewRay {
     F3 o, d;
@@ -1154,7 +1319,7 @@ __device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
 // LA: consumes the result of a next-event sample that is not the last one of its vertex, of a closest-hit ray
 // that found a surface, or of a probe ray; enters the vertex if it is new; sets up the next next-event sample.
 // Returns PH3_NONE when a ray was emitted into nr, else the phase the path has to visit instead.
-template <int MODE>
+template <int MODE, bool RING = false>
 __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false>& tb, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr,
                                             PathCounters& cnt, const bool trace_all)
 {
@@ -1164,7 +1329,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // that waits issues nothing: everything whose address is known is fetched up front, needed by this lane's stage or not.
     //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id(P, g);
+    const uint4 idv = load_path_id<RING>(P, g);
     const float4 vn = gld(&pl.vn[g]);
     const float4 cc = gld(&pl.cc[g]); // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
@@ -1313,12 +1478,12 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
 }
 
 // LB: direct light of vertex `depth` is complete -> vertex record, Russian roulette, bounce (Render.cuh:210-228).
-template <int MODE>
+template <int MODE, bool RING = false>
 __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id(P, g);
+    const uint4 idv = load_path_id<RING>(P, g);
     const float4 cc = gld(&pl.cc[g]); // (with the other planes, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
@@ -1348,27 +1513,35 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
 }
 
 // LC: the path is complete (miss, emitter, roulette, stack full) -> backward recursion (Render.cuh:238-326), next
-// work item and its camera ray (Render.cuh:344-347).  Returns false when the work items are exhausted (the ray slot dies).
-__device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr)
+// work item and its camera ray (Render.cuh:344-347).  Returns LC_DEAD when the work items are exhausted (the ray slot dies), LC_RAY
+// with the camera ray of a new path, or -- commit ring only -- LC_WAIT: the slot holds a work item it may not start yet and comes
+// back to this phase.  fin_key: see ring_publish.
+enum { LC_DEAD = 0, LC_RAY = 1, LC_WAIT = 2 };
+template <bool RING>
+__device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr, uint32_t& fin_key)
 {
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id(P, g); // (with la, not after the stage is known: one round trip less, see logic_A)
+    const uint4 idv = load_path_id<RING>(P, g); // (with la, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
+    constexpr bool ring = RING;
+    const bool waiting = ring && stage == ST_WAIT;
     // The next work item is asked for NOW -- one atomic on the wave's home cursor for all its lanes -- and looked at after the
     // backward recursion: the cursor's round trip hides behind the recursion's own loads (the earlier attempt read the answer with
     // a readfirstlane at once, which waits).  A home shard that has run dry (the end of a launch) falls back to grab_item below.
-    const uint32_t home_ = blockIdx.x & (ITEM_SHARDS - 1);
+    const uint32_t home_ = RING ? blockIdx.x & (P.ring_shards - 1u) : blockIdx.x & (ITEM_SHARDS - 1);
     const uint32_t lo_ = home_ * P.items_per_shard, hi_ = min(lo_ + P.items_per_shard, P.n_items);
-    const unsigned long long gmask_ = __ballot(1);
+    const unsigned long long gmask_ = __ballot(!waiting);
     const int lane_ = threadIdx.x & 63;
     const uint32_t grank_ = (uint32_t)__popcll(gmask_ & ((1ull << lane_) - 1ull));
     unsigned int pre_base_ = 0;
-    const bool pre_ok_ = lo_ < P.n_items;
+    const bool pre_ok_ = lo_ < P.n_items && gmask_ != 0ull;
     if (pre_ok_ && lane_ == __ffsll((long long)gmask_) - 1) pre_base_ = __hip_atomic_fetch_add((CRT_GAS unsigned int*)(P.item_next + home_ * ITEM_STRIDE), (unsigned int)__popcll(gmask_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (stage != ST_NEW) {
+    uint32_t home_word_ = 0;
+    if (RING) home_word_ = ring_load(P.ring_state + home_ * ITEM_STRIDE);
+    if (stage != ST_NEW && !waiting) {
         int deepest = (int)depth;
         bool emissive = false;
         F3 ke = f3(0.0f, 0.0f, 0.0f);
@@ -1379,33 +1552,52 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
             ke = f3(m2.x, m2.y, m2.z);
         }
         const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
-        // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
-        // and the scene in L2
-        __builtin_nontemporal_store(L.x, (CRT_GAS float*)&P.L[idv.z].x);
-        __builtin_nontemporal_store(L.y, (CRT_GAS float*)&P.L[idv.z].y);
-        __builtin_nontemporal_store(L.z, (CRT_GAS float*)&P.L[idv.z].z);
+        if (ring) {
+            const uint32_t sh = fast_div(idv.z, P.items_per_shard_div.m, P.items_per_shard_div.sh), c = idv.z - sh * P.items_per_shard;
+            const uint32_t s = fast_div(c, P.spsh_div.m, P.spsh_div.sh), rs = s & P.ring_mask;
+            float4* Lr = P.L + (size_t)rs * P.ring_stride + (size_t)sh * P.spsh + (c - s * P.spsh);
+            ring_storef(&Lr->x, L.x); ring_storef(&Lr->y, L.y); ring_storef(&Lr->z, L.z);
+            fin_key = (sh << 16) | rs;
+        } else {
+            // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
+            // and the scene in L2
+            __builtin_nontemporal_store(L.x, (CRT_GAS float*)&P.L[idv.z].x);
+            __builtin_nontemporal_store(L.y, (CRT_GAS float*)&P.L[idv.z].y);
+            __builtin_nontemporal_store(L.z, (CRT_GAS float*)&P.L[idv.z].z);
+        }
     }
-    bool first_ = pre_ok_;
+    bool first_ = pre_ok_ && !waiting;
     for (;;) {
         uint32_t item = ITEM_NONE;
-        if (first_) { // the answer of the atomic issued above (the leader is the first active lane)
-            const unsigned long long idx_ = (unsigned long long)lo_ + (unsigned int)__builtin_amdgcn_readfirstlane((int)pre_base_) + grank_;
-            if (idx_ < hi_) item = (uint32_t)idx_;
-            first_ = false;
-        }
-        if (item == ITEM_NONE) item = grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
-        if (item == ITEM_NONE) return false;
-        if (P.item_list) { // the tail of every cursor shard is handed out "paths that stop at their first vertex last" (k_order_items)
-            const uint32_t sh_ = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh);
-            const uint32_t slo_ = sh_ * P.items_per_shard, shi_ = min(slo_ + P.items_per_shard, P.n_items);
-            const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
-            if (item >= wlo_) item = gld(&P.item_list[sh_ * P.order_window + (item - wlo_)]);
+        if (waiting) item = idv.z; // the item this slot was handed earlier
+        else {
+            if (first_) { // the answer of the atomic issued above (the leader is the first active lane)
+                const unsigned long long idx_ = (unsigned long long)lo_ + (unsigned int)__builtin_amdgcn_readfirstlane((int)pre_base_) + grank_;
+                if (idx_ < hi_) item = (uint32_t)idx_;
+                first_ = false;
+            }
+            if (item == ITEM_NONE) item = RING ? grab_item_ring(P.item_next, P.items_per_shard, P.ring_shards, home_)
+                                               : grab_item(nullptr, P.item_next, P.items_per_shard, P.n_items, blockIdx.x & (ITEM_SHARDS - 1));
+            if (item == ITEM_NONE) return LC_DEAD;
+            if (P.item_list) { // the tail of every cursor shard is handed out "paths that stop at their first vertex last" (k_order_items)
+                const uint32_t sh_ = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh);
+                const uint32_t slo_ = sh_ * P.items_per_shard, shi_ = min(slo_ + P.items_per_shard, P.n_items);
+                const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
+                if (item >= wlo_) item = gld(&P.item_list[sh_ * P.order_window + (item - wlo_)]);
+            }
         }
         bool valid; uint32_t pi, pj, pixel_index, k;
-        decode_item(P, item, pixel_index, k, valid, pi, pj);
+        decode_item<RING>(P, item, pixel_index, k, valid, pi, pj);
         if (!valid) continue; // padding slot of a ragged tile: take another item
+        if (ring && !ring_gate_open(P, item, home_, home_word_)) { // its sample's slot of the ring is not free yet: hold the item
+            if (!waiting) {
+                store_path_id(P, g, item);
+                gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_WAIT << 8)));
+            }
+            return LC_WAIT;
+        }
         cnt.paths++;
-        store_path_id(P, g, item);
+        if (!waiting) store_path_id(P, g, item);
         const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
         const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
         const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;
@@ -1415,7 +1607,7 @@ __device__ __forceinline__ bool logic_C(const LParams& P, const Tables<false>& t
                          P.inv_view[2] * cd.x + (P.inv_view[5] * cd.y + P.inv_view[8] * cd.z));
         gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_HIT << 8)));
         nr.o = f3(P.eye[0], P.eye[1], P.eye[2]); nr.d = unit3(wd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
-        return true;
+        return LC_RAY;
     }
 }
 
@@ -1699,9 +1891,12 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 #define CRT_SORT4(mode) ((mode) != 2)
 // ALL: every next-event sample is traced (CRT_FLAG_TRACE_ALL) -- its own instantiation, so that profiles of the default path
 // are not mixed with it
-template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false>
+// RING: the commit ring (in-order sum of the samples inside the launch, see ring_publish) -- its own instantiations: the kernels
+// without it are, instruction for instruction, what they were before it existed
+template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false, bool RING = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, CRT_WAVES))) void k_mega3(const MParams3 M3)
 {
+    static_assert(!(RING && (QUERY || STATS)), "the commit ring is a render without counters");
     static_assert(!(R16 && MODE == 1), "CRT_TRAVERSAL_REFERENCE walks the 2-wide trees: 32-bit stack entries");
     typedef Pool3LdsT<R16> LDS3;
     __shared__ LDS3 S;
@@ -1725,6 +1920,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     int qn[PH3_N], qh[PH3_N], qt[PH3_N]; // entries, head, tail (head and tail in [0, POOL3_QCAP))
 #pragma unroll
     for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; qt[p] = 0; }
+    constexpr bool commit_ring = RING;
+    if (commit_ring && lane == 0) S.waitq = 0u;
     // every ray of the pool starts in LC with a path in stage NEW
     {
         const int n_valid = (int)min((uint32_t)POOL3_P, pl.n > base ? pl.n - base : 0u);
@@ -1919,14 +2116,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 leaf_arm(std::true_type{});
         }
       }
-        if (act == PH3_NONE) break;
+        // (commit ring: a pool with nothing to do but slots that are held back looks at those)
+        if (act == PH3_NONE && !(commit_ring && (__builtin_amdgcn_readfirstlane((int)S.waitq) & 0xff) != 0)) break;
         if (act == PH3_LA) {
             POP3(PH3_LA)
             bool new_exact = false;
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_A<MODE>(Pl, tl, g, S.A[id], S.B[id], nr, cnt, ALL);
+                nph = logic_A<MODE, RING>(Pl, tl, g, S.A[id], S.B[id], nr, cnt, ALL);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
@@ -1937,22 +2135,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_B<MODE>(Pl, g, S.A[id], S.B[id], nr);
+                nph = logic_B<MODE, RING>(Pl, g, S.A[id], S.B[id], nr);
                 if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
         } else {
-            POP3(PH3_LC)
-            bool new_exact = false;
+            // LC, or -- commit ring -- a look at the slots that are held back (PH3_WAIT), through the same code: the held slots have
+            // their turn when the pool has nothing else to do and, while there are any, at every second visit of this phase
+            // (no loop around the phase: it would count as one more level of nesting in the compiler's register allocation)
+            int wn = 0, wh = 0, wt = 0; // ring PH3_WAIT: entries, head, tail
+            bool held = false;
+            if (commit_ring) {
+                const uint32_t wq = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.waitq);
+                wn = (int)(wq & 0xffu); wh = (int)((wq >> 8) & 0xffu); wt = (int)((wq >> 16) & 0xffu);
+                held = act == PH3_NONE || (wn > 0 && (wq >> 24) != 0u);
+            }
+            const int src_n = held ? wn : qn[PH3_LC], src_h = held ? wh : qh[PH3_LC];
+            const int take = min(64, src_n);
+            const bool on = lane < take;
+            const uint32_t id = (held ? S.ring[PH3_WAIT] : S.ring[PH3_LC])[ring_wrap((uint32_t)(src_h + lane))];
+            {
+                int nh = src_h + take;
+                if (nh >= POOL3_QCAP) nh -= POOL3_QCAP;
+                if (held) { wh = nh; wn -= take; } else { qh[PH3_LC] = nh; qn[PH3_LC] -= take; }
+            }
+            const uint32_t g = base + id;
+            uint32_t nph = PH3_NONE;
+            bool new_exact = false, wait = false;
+            uint32_t fin_key = ~0u;
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                if (QUERY ? query_C(Pl, g, S.A[id], S.B[id], nr) : logic_C(Pl, tl, g, cnt, nr))
-                    nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                const int got = QUERY ? (query_C(Pl, g, S.A[id], S.B[id], nr) ? LC_RAY : LC_DEAD) : logic_C<RING>(Pl, tl, g, cnt, nr, fin_key);
+                if (got == LC_RAY) nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                wait = got == LC_WAIT;
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
+            if (commit_ring) { // count the finished work items, commit what that completes; park the slots that are held back
+                LOGIC_PARAMS()
+                ring_publish(Pl, fin_key);
+                const unsigned long long mw = __ballot(wait);
+                if (mw) {
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, (uint32_t)wt));
+                    if (wait) S.ring[PH3_WAIT][ring_wrap(slot)] = (uint8_t)id;
+                    const int add = (int)__popcll(mw);
+                    wn += add;
+                    wt += add;
+                    if (wt >= POOL3_QCAP) wt -= POOL3_QCAP;
+                }
+                if (held && mw == __ballot(on)) __builtin_amdgcn_s_sleep(64); // (none of them may start yet: no hurry)
+                if (lane == 0) S.waitq = (uint32_t)wn | ((uint32_t)wh << 8) | ((uint32_t)wt << 16) | (held ? 0u : 1u << 24);
+            }
         }
     }
 #undef PUSH3
@@ -2029,6 +2264,7 @@ __device__ __forceinline__ FastDiv make_fastdiv_dev(uint32_t d)
 // end of every shard the fixed cost of a launch drops from 2.5 ms to about 1 ms (tools/share_probe.py: a rank's share of C2 at 1 / 2 / 4 /
 // 8 ranks 107.3 / 54.9 / 28.4 / 15.9 ms without, 106.8 / 54.1 / 27.5 / 14.6 ms with, this pass included).  One wave orders a span of
 // 1 024 items of one shard with two atomics (a cache line per counter).
+template <bool RING>
 __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* list, unsigned int* cnt)
 {
     const uint32_t spans = (P.order_window + 1023u) / 1024u;
@@ -2047,7 +2283,7 @@ __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* l
         const uint32_t i = b + j * 64u + lane;
         if (i < hi) {
             bool valid; uint32_t pi, pj, pixel_index, k;
-            decode_item(P, i, pixel_index, k, valid, pi, pj);
+            decode_item<RING>(P, i, pixel_index, k, valid, pi, pj);
             exists |= 1u << j;
             // the roulette of the first vertex, as logic_B draws it (Render.cuh:223-227)
             if (valid && !(rng_uniform(rng_draw(P.seed, pixel_index, k, 0, RNG_BOUNCE, 0).x) > P.p_rr)) goes_on |= 1u << j;
@@ -2217,6 +2453,18 @@ template <typename T> struct DevBuf {
     {
         if (n < count) alloc(count);
     }
+    // Uncached device memory: every access goes to memory, past the L2 caches of the XCDs, which are not coherent with one another
+    // inside a launch (the commit ring's buffers: written by one wave, read by another during the same launch).
+    void ensure_uncached(size_t count)
+    {
+        if (n >= count && uncached) return;
+        release();
+        if (count == 0) count = 1;
+        HIP_CHECK(hipExtMallocWithFlags((void**)&p, count * sizeof(T), hipDeviceMallocUncached));
+        n = count;
+        uncached = true;
+    }
+    bool uncached = false;
     void upload(const std::vector<T>& v)
     {
         alloc(v.size());
@@ -2224,7 +2472,7 @@ template <typename T> struct DevBuf {
     }
     void release()
     {
-        if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+        if (p) { (void)hipFree(p); p = nullptr; n = 0; uncached = false; }
     }
     ~DevBuf() { release(); }
 };
@@ -2250,6 +2498,11 @@ struct crt_scene {
     DevBuf<unsigned long long> counters;      // [CNT_SHARDS][CNT_STRIDE]
     DevBuf<unsigned int> item_next;           // [ITEM_SHARDS][ITEM_STRIDE]
     DevBuf<uint32_t> item_list;               // k_order_items: the order of the work items of a launch (small launches only)
+    DevBuf<unsigned int> ring_done, ring_state; // commit ring: finished items per (shard, sample), shard words
+    DevBuf<float4> ring_L;                      // commit ring: radiance of [ring samples][shards * slots per shard] (uncached memory)
+    std::vector<unsigned int> ring_state_host;
+    uint64_t last_radiance_bytes = 0;           // per-work-item (or ring) radiance storage the last render used
+    uint32_t last_ring_samples = 0;             // its ring size in samples (0: one radiance per work item)
     DevBuf<unsigned int> order_cnt;           // [ITEM_SHARDS][2] counters, one 128 B line each
     DevBuf<unsigned int> slot_next[2];        // [SLOT_SHARDS][SLOT_STRIDE], one per pool half
     DevBuf<int2> spill[2];                    // traversal stack overflow, one per pool half
@@ -2449,6 +2702,7 @@ int validate_desc(const crt_scene_desc* d)
 struct Shard {
     uint32_t tiles_x, tiles_y, n_tiles, local_tiles, nslots;
 };
+struct RingPlan { uint32_t samples, spsh, shards; }; // commit ring of a launch: samples held (0 = one radiance per work item), pixel slots per cursor shard
 Shard make_shard(uint32_t w, uint32_t h, uint32_t world)
 {
     Shard s;
@@ -2474,8 +2728,17 @@ uint32_t env_u32(const char* name, uint32_t dflt)
 // The instantiation of k_mega3 for a traversal mode (0 FAST, 1 REFERENCE, 2 EXACT), with or without counters, every sample traced
 // or not (FAST only), render or query form, 32- or 16-bit stack entries (never for REFERENCE)
 typedef void (*Mega3Kernel)(const MParams3);
-Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16)
+Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring = false)
 {
+    if (ring) { // (a render without counters)
+        if (mode == 1) return (Mega3Kernel)k_mega3<1, false, false, false, false, true>;
+        if (mode == 2) {
+            if (all) return r16 ? (Mega3Kernel)k_mega3<2, false, true, false, true, true> : (Mega3Kernel)k_mega3<2, false, true, false, false, true>;
+            return r16 ? (Mega3Kernel)k_mega3<2, false, false, false, true, true> : (Mega3Kernel)k_mega3<2, false, false, false, false, true>;
+        }
+        if (all) return r16 ? (Mega3Kernel)k_mega3<0, false, true, false, true, true> : (Mega3Kernel)k_mega3<0, false, true, false, false, true>;
+        return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, false, false, true>;
+    }
     if (mode == 1) return query ? (Mega3Kernel)k_mega3<1, false, false, true> : stats ? (Mega3Kernel)k_mega3<1, true> : (Mega3Kernel)k_mega3<1, false>;
     if (query) {
         if (mode == 2) return r16 ? (Mega3Kernel)k_mega3<2, false, false, true, true> : (Mega3Kernel)k_mega3<2, false, false, true, false>;
@@ -2513,7 +2776,7 @@ bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t s
     static std::vector<unsigned long long> sum(N_CNT, 0ull);
     if (!fn) {
         HIP_CHECK(hipModuleLoad(&mod, co));
-        HIP_CHECK(hipModuleGetFunction(&fn, mod, "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1EEEvNS_8MParams3E"));
+        HIP_CHECK(hipModuleGetFunction(&fn, mod, "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0EEEvNS_8MParams3E"));
         HIP_CHECK(hipMalloc((void**)&buf, 2 * (size_t)N_CNT * STRIDE));
         // the prologues add block offsets to the low address word without a carry: the counters must not straddle a 4 GiB boundary
         cnt = buf;
@@ -2631,13 +2894,42 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         const uint64_t max_items = std::min<uint64_t>(kMaxChunkItems, 1ull << std::min(30u, env_u32("CRT_CHUNK_LOG2", 30))); // (test hook: small chunks)
         uint32_t chunk = (uint32_t)std::min<uint64_t>(s_count, std::max<uint64_t>(1, max_items / sh.nslots));
         uint64_t cap = (uint64_t)chunk * sh.nslots;
+        const uint32_t pipeline = choose_pipeline(sc);
+        // ---- commit ring (megakernel only, CRT_FLAG_BOUNDED_RADIANCE): radiance storage for a window of samples, the sum
+        // c += L_k / spp made inside the launch; the whole sample range is then ONE launch.  ring samples = 4 x the depth of the work in
+        // flight (pool slots / pixel slots), at least 32: a shard is held back only when one of its paths takes four times as long as
+        // the rest of the pool.
+        RingPlan ring;
+        std::memset(&ring, 0, sizeof(ring));
+        if (pipeline == 4 && !want_stats) {
+            // cursor shards: the commits of a shard are a serial chain (one wave, a memory round trip per 256 pixel slots), so a ring
+            // launch has more and smaller shards than the 64 of a launch without: about 1 024 pixel slots each, at most 1 024 shards
+            uint32_t shards = ITEM_SHARDS;
+            while (shards < 1024u && sh.nslots / (shards * 2u) >= 1024u) shards *= 2u;
+            const uint32_t spsh = ((sh.nslots + shards - 1) / shards + 63u) & ~63u;
+            const uint64_t pool_slots = (uint64_t)sc->n_cus * 16u * (uint64_t)POOL3_P;
+            uint32_t rs = 32;
+            while (rs < 65536u && (uint64_t)rs * sh.nslots < 4ull * pool_slots) rs <<= 1;
+            const uint32_t forced = env_u32("CRT_COMMIT_RING_LOG2", 0); // (test hook: a ring of 2^n samples, with or without the flag)
+            if (forced) rs = 1u << std::min(16u, forced);
+            const uint64_t per_shard = (uint64_t)spsh * s_count;
+            const bool fits32 = per_shard * shards < 0xffffffffull;
+            if ((forced || (prm->flags & CRT_FLAG_BOUNDED_RADIANCE)) && rs < s_count && fits32) {
+                ring.samples = rs; ring.spsh = spsh; ring.shards = shards;
+                chunk = s_count;
+                cap = (uint64_t)rs * spsh * shards;
+            }
+        }
         const uint32_t pool_log2 = std::min(26u, std::max(8u, env_u32("CRT_POOL_LOG2", 22)));
         const uint32_t pool_n = (uint32_t)std::min<uint64_t>((cap + 255) / 256 * 256, 1ull << pool_log2);
         const int batch_max = (int)std::min<uint32_t>(kMaxBatch, env_u32("CRT_ROUND_BATCH", 16));
         int batch = batch_max;
 
-        sc->L.ensure(cap);
-        sc->accum.ensure((size_t)sh.nslots * 3);
+        if (ring.samples) sc->ring_L.ensure_uncached(cap);
+        else sc->L.ensure(cap);
+        sc->last_radiance_bytes = cap * sizeof(float4);
+        sc->last_ring_samples = ring.samples;
+        sc->accum.ensure_uncached((size_t)sh.nslots * 3); // (always uncached: a progressive render may switch between launches with and without the ring)
         const bool timing = stats != nullptr;
         if (timing && sc->ev.size() < (size_t)(4 * kMaxBatch + 4)) {
             while (sc->ev.size() < (size_t)(4 * kMaxBatch + 4)) {
@@ -2655,7 +2947,6 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
         };
         unsigned long long alive_seen = 0;
 
-        const uint32_t pipeline = choose_pipeline(sc);
         if (pipeline == 4) {
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
@@ -2664,7 +2955,7 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             const int mode_id = (reference ? 2 : exact ? 4 : 0) + (want_stats ? 1 : 0);
             const int mode3 = reference ? 1 : exact ? 2 : 0;
             const bool r16 = use_ref16(sc, mode3);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16, ring.samples != 0);
             const uint32_t pool_p = (uint32_t)POOL3_P;
             MParams M;
             std::memset(&M, 0, sizeof(M));
@@ -2678,7 +2969,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 };
                 q3(&per_cu);
                 per_cu = (int)std::min<uint32_t>((uint32_t)per_cu, env_u32("CRT_MEGA_BLOCKS_PER_CU", 64));
-                blocks = std::min<uint32_t>((uint32_t)((cap + pool_p - 1) / pool_p), (uint32_t)(sc->n_cus * per_cu));
+                const uint64_t most_items = ring.samples ? (uint64_t)s_count * sh.nslots : cap;
+                blocks = std::min<uint32_t>((uint32_t)std::min<uint64_t>((most_items + pool_p - 1) / pool_p, 0x7fffffffull), (uint32_t)(sc->n_cus * per_cu));
                 lanes = blocks * pool_p; // pool slots
             }
             sc->p_vx.ensure(lanes); sc->p_la.ensure(lanes); sc->p_cc.ensure(lanes); sc->p_vn.ensure(lanes); sc->p_id.ensure(lanes);
@@ -2721,6 +3013,25 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 P.sample_begin = s0;
                 P.n_items = (uint32_t)((uint64_t)ns * sh.nslots);
                 P.items_per_shard = ((P.n_items + ITEM_SHARDS - 1) / ITEM_SHARDS + 63u) & ~63u;
+                if (ring.samples) { // cursor shard = ring.spsh pixel slots x ns samples
+                    P.items_per_shard = ring.spsh * ns;
+                    P.n_items = P.items_per_shard * ring.shards;
+                    P.ring_mask = ring.samples - 1u; P.spsh = ring.spsh; P.spsh_div = make_fastdiv(ring.spsh); P.ring_shards = ring.shards;
+                    P.ring_stride = ring.spsh * ring.shards; P.n_samples = ns; P.tail_first = P.items_per_shard; P.spp_f = (float)prm->spp;
+                    sc->ring_done.ensure_uncached((size_t)ring.shards * ring.samples);
+                    sc->ring_state.ensure_uncached((size_t)ring.shards * ITEM_STRIDE);
+                    P.ring_done = sc->ring_done.p; P.ring_state = sc->ring_state.p; P.accum = sc->accum.p; P.L = sc->ring_L.p;
+                    std::vector<unsigned int>& state = sc->ring_state_host; // (a member: the copy below may still read it after this scope)
+                    state.assign((size_t)ring.shards * ITEM_STRIDE, 0u);
+                    for (uint32_t slot = 0; slot < sh.nslots; slot++) { // word 1: the pixel slots of the shard that are pixels
+                        const uint32_t tile = (slot >> 6) * prm->world + prm->rank, pix = slot & 63u;
+                        if (tile >= sh.n_tiles) continue;
+                        const uint32_t ty = tile / sh.tiles_x, tx = tile - ty * sh.tiles_x;
+                        if (tx * CRT_TILE + (pix & 7u) < prm->width && ty * CRT_TILE + (pix >> 3) < prm->height) state[(size_t)(slot / ring.spsh) * ITEM_STRIDE + 1]++;
+                    }
+                    HIP_CHECK(hipMemcpyAsync(sc->ring_state.p, state.data(), state.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+                    HIP_CHECK(hipMemsetAsync(sc->ring_done.p, 0, (size_t)ring.shards * ring.samples * sizeof(unsigned int), st));
+                }
                 // the paths that stop at their first vertex are handed out last (k_order_items): 1 % of a whole C2 frame on one GPU,
                 // 8 % of a rank's share on eight.  CRT_ITEM_ORDER=0 switches it off.
                 P.item_list = nullptr;
@@ -2732,18 +3043,25 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                         // order 107.3 / 54.9 / 28.4 / 15.9 ms; 2^17: 107.4 / 54.5 / 28.3 / 15.2; 2^19: 106.8 / 54.2 / 27.7 / 14.6; whole shards:
                         // 107.2 / 54.1 / 27.5 / 14.6 -- the pass itself costs 0.9 ms for the 245.8 M items of a whole frame)
                         P.order_window = std::min<uint32_t>(P.items_per_shard, env_u32("CRT_ORDER_WINDOW", 1u << 19));
+                        if (ring.samples) { // the window may span half the ring: its items stand for the launch's last sample at the gate
+                            P.order_window = std::min<uint32_t>(P.order_window, (ring.samples / 2u) * ring.spsh);
+                            P.tail_first = P.items_per_shard - P.order_window;
+                        }
                         P.items_per_shard_div = make_fastdiv(std::max(1u, P.items_per_shard));
-                        sc->item_list.ensure((size_t)ITEM_SHARDS * P.order_window);
-                        sc->order_cnt.ensure((size_t)ITEM_SHARDS * 2 * 32);
-                        HIP_CHECK(hipMemsetAsync(sc->order_cnt.p, 0, (size_t)ITEM_SHARDS * 2 * 32 * sizeof(unsigned int), st));
+                        const uint32_t n_sh = ring.samples ? ring.shards : (uint32_t)ITEM_SHARDS;
+                        sc->item_list.ensure((size_t)n_sh * P.order_window);
+                        sc->order_cnt.ensure((size_t)n_sh * 2 * 32);
+                        HIP_CHECK(hipMemsetAsync(sc->order_cnt.p, 0, (size_t)n_sh * 2 * 32 * sizeof(unsigned int), st));
                         const uint32_t spans = (P.order_window + 1023u) / 1024u;
-                        hipLaunchKernelGGL(k_order_items, dim3(ITEM_SHARDS * spans), dim3(64), 0, st, P, sc->item_list.p, sc->order_cnt.p);
+                        if (ring.samples) hipLaunchKernelGGL(k_order_items<true>, dim3(ring.shards * spans), dim3(64), 0, st, P, sc->item_list.p, sc->order_cnt.p);
+                        else hipLaunchKernelGGL(k_order_items<false>, dim3(ITEM_SHARDS * spans), dim3(64), 0, st, P, sc->item_list.p, sc->order_cnt.p);
                         HIP_CHECK(hipGetLastError());
                         P.item_list = sc->item_list.p;
                     }
                 }
+                P.items_per_shard_div = make_fastdiv(std::max(1u, P.items_per_shard));
                 M.P = P;
-                HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), st));
+                HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)(ring.samples ? ring.shards : (uint32_t)ITEM_SHARDS) * ITEM_STRIDE * sizeof(unsigned int), st));
                 if (timing) HIP_CHECK(hipEventRecord(e1, st));
                 if (s0 == s_begin) HIP_CHECK(hipEventRecord(sc->ev_k0, st));
                 {
@@ -2767,8 +3085,11 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
                 sc->last_launches = launches;
                 A.chunk_samples = ns;
                 A.first_chunk = s0 == 0; A.last_chunk = s0 + ns >= prm->spp;
-                hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
-                HIP_CHECK(hipGetLastError());
+                if (ring.samples) { A.chunk_samples = 0; A.first_chunk = 0; } // the sum is in the accumulator already: tone mapping only
+                if (!ring.samples || A.last_chunk) {
+                    hipLaunchKernelGGL(k_accumulate, dim3((sh.nslots + 255) / 256), dim3(256), 0, st, A);
+                    HIP_CHECK(hipGetLastError());
+                }
                 sc->acc.samples = A.last_chunk ? 0u : s0 + ns; sc->acc.spp = prm->spp; sc->acc.width = prm->width; sc->acc.height = prm->height;
                 sc->acc.rank = prm->rank; sc->acc.world = prm->world; sc->acc.tiled = tiled ? 1u : 0u;
             }
@@ -3230,7 +3551,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->nodes.upload(nodes); sc->tri_geo.upload(geo); sc->tri_mat.upload(tri_mat); sc->mats.upload(mats);
         sc->ltri.upload(ltri); sc->lights.upload(lights); sc->leaf_count.upload(leaf_count);
         sc->counters.alloc((size_t)CNT_SHARDS * CNT_STRIDE);
-        sc->item_next.alloc((size_t)ITEM_SHARDS * ITEM_STRIDE);
+        sc->item_next.alloc((size_t)1024 * ITEM_STRIDE); // (a commit-ring launch has up to 1 024 cursor shards)
         sc->slot_next[0].alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
         sc->slot_next[1].alloc((size_t)SLOT_SHARDS * SLOT_STRIDE);
         HIP_CHECK(hipStreamCreateWithFlags(&sc->aux_stream, hipStreamNonBlocking));
@@ -3349,6 +3670,14 @@ int crt_last_launch_ms(crt_scene* sc, float* ms, uint32_t* launches)
     hipError_t e = hipEventElapsedTime(ms, sc->ev_k0, sc->ev_k1);
     if (e != hipSuccess) return fail(CRT_ERR_HIP, std::string("crt_last_launch_ms: hipEventElapsedTime: ") + hipGetErrorString(e) + " (synchronize the stream first)");
     if (launches) *launches = sc->last_launches;
+    return CRT_OK;
+}
+
+int crt_radiance_storage(crt_scene* sc, uint64_t* bytes, uint32_t* ring_samples)
+{
+    if (!sc || !bytes) return fail(CRT_ERR_INVALID_ARG, "crt_radiance_storage: null argument");
+    *bytes = sc->last_radiance_bytes;
+    if (ring_samples) *ring_samples = sc->last_ring_samples;
     return CRT_OK;
 }
 

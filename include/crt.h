@@ -126,8 +126,15 @@ enum {
     CRT_FLAG_TILED_OUTPUT = 2u,  /* write this rank's pixels in compact 8x8-tile order instead of row-major */
     CRT_FLAG_TRACE_ALL = 8u,     /* CRT_TRAVERSAL_EXACT / _FAST trace every next-event sample, also those whose contribution is exactly
                                     zero (crt_stats.rays_untraced stays 0); same frame, for measuring the traversal alone */
-    CRT_FLAG_FORCE_EXACT = 4u    /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
+    CRT_FLAG_FORCE_EXACT = 4u,   /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
                                     box arithmetic on the reference topology, still pruned / any-hit); results are unchanged */
+    CRT_FLAG_BOUNDED_RADIANCE = 16u /* keep the radiance of a WINDOW of samples instead of one value per path: the frame's sum c += L_k / spp
+                                    (Render.cuh:348) is made in sample order inside the launch ("commit ring"), the
+                                    whole sample range is one launch whatever its size, and the handle needs 16 B x pixels x 32 ... 64
+                                    samples (245 MB for 800x600) instead of 16 B per path (3.9 GB for 800x600 spp 512; 17 GB per 2^30 paths).
+                                    Same bits.  Costs time (800x600 spp 512: 167 ms instead of 93): off by default -- memory is what this
+                                    device has plenty of.  Ignored with CRT_FLAG_STATS, by the fallback pipeline, and when the sample range
+                                    is no longer than the window */
 };
 
 typedef struct {
@@ -213,6 +220,10 @@ int crt_render_device(crt_scene* scene, const crt_camera* cam, const crt_params*
  * events recorded on the frame's stream without synchronizing): lets a caller that pipelines frames with crt_render_device(stats = NULL)
  * read every frame's kernel time afterwards.  The frame's stream must have been synchronized (CRT_ERR_HIP otherwise). */
 int crt_last_launch_ms(crt_scene* scene, float* ms, uint32_t* launches);
+
+/* Bytes of per-path radiance storage the handle's last render used, and the size of its commit ring in samples (0 = one radiance per
+ * path of a chunk; see CRT_FLAG_BOUNDED_RADIANCE). */
+int crt_radiance_storage(crt_scene* scene, uint64_t* bytes, uint32_t* ring_samples);
 
 /* Progressive rendering (the reference re-renders all spp on every click, src/main.cu:368-377):
  * renders samples [sample_begin, sample_begin + sample_count) of params->spp into the accumulator the scene handle

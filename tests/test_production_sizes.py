@@ -78,6 +78,15 @@ def test_c4_full_size_on_one_device_in_two_launches():
         assert np.array_equal(rgb_all, rgb)
         assert np.array_equal(util.bits(one.mean_buffer), util.bits(mean))
         one.extra_flags = 0
+        # ... in ONE launch with the commit ring (CRT_FLAG_BOUNDED_RADIANCE): 32 samples of radiance instead of 2^30 paths'
+        full_bytes = one.radiance_storage()[0]
+        one.extra_flags = crt.FLAG_BOUNDED_RADIANCE
+        rgb_ring = one.run_view(eye, iv, fov, width=w, height=h)
+        assert one.stats["kernel_launches"] == 1 and one.stats["rays"] == st["rays"]
+        ring_bytes, ring_samples = one.radiance_storage()
+        assert ring_samples == 32 and ring_bytes * 4 <= full_bytes   # (32 samples x 8.3 M pixels against 2^30 paths)
+        assert np.array_equal(rgb_ring, rgb) and np.array_equal(util.bits(one.mean_buffer), util.bits(mean))
+        one.extra_flags = 0
         # ... and the exhaustive REFERENCE traversal of the same 7.9 G rays, and CRT_TRAVERSAL_FAST (the default mode plus distance pruning,
         # whose rule is not a theorem: the full-size C3 frame once found a ray it lost, csrc/crt_trace.h)
         for mode in (crt.TRAVERSAL_REFERENCE, crt.TRAVERSAL_FAST):
