@@ -269,6 +269,15 @@ __device__ __forceinline__ unsigned int ring_load(const unsigned int* p) { retur
 __device__ __forceinline__ float ring_loadf(const float* p) { return __uint_as_float(__hip_atomic_load((ring_word_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void ring_storef(float* p, const float v) { __hip_atomic_store((ring_word_ptr)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ring_wait_mem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A path's radiance as ONE 16-byte store with the scope bits of an agent-scope atomic store (what ring_storef's instruction carries,
+// four times as wide: three 4-byte write-through stores per path were a fifth of the ring's cost).  The compiler does not count it;
+// ring_publish waits for everything outstanding before the path is counted.
+__device__ __forceinline__ void ring_store16(float4* p, const float x, const float y, const float z)
+{
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v4f_ v; v.x = x; v.y = y; v.z = z; v.w = 0.0f;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
 #define RING_BUSY 0x80000000u
 
 // May the work item be started?  (in-shard position c: items of the ordered tail window stand for the last sample)
@@ -1556,7 +1565,7 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
             const uint32_t sh = fast_div(idv.z, P.items_per_shard_div.m, P.items_per_shard_div.sh), c = idv.z - sh * P.items_per_shard;
             const uint32_t s = fast_div(c, P.spsh_div.m, P.spsh_div.sh), rs = s & P.ring_mask;
             float4* Lr = P.L + (size_t)rs * P.ring_stride + (size_t)sh * P.spsh + (c - s * P.spsh);
-            ring_storef(&Lr->x, L.x); ring_storef(&Lr->y, L.y); ring_storef(&Lr->z, L.z);
+            ring_store16(Lr, L.x, L.y, L.z);
             fin_key = (sh << 16) | rs;
         } else {
             // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
