@@ -5,7 +5,7 @@
 // The GUI-settable knobs (spp, P_RR, light_sample_n, eye/lookat/up: Gui.h) are flags.
 //
 //   crt_cli <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]
-//           [--eye x y z] [--lookat x y z] [--up x y z] [--reference | --exact | --fast] [--base-dir DIR] [--device N]
+//           [--eye x y z] [--lookat x y z] [--up x y z] [--reference | --exact | --fast] [--bounded-radiance] [--base-dir DIR] [--device N]
 //           [--gpus N | --devices a,b,...] [--gather auto|rccl|copy]
 // --gpus N renders on devices 0..N-1 of this node in one process (crt_multi: interleaved pixel tiles, one RCCL all-gather);
 // --devices names the device of every rank explicitly (a repeated index puts two ranks on one GPU: --gather copy only).
@@ -23,7 +23,7 @@ int main(int argc, char** argv)
 {
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s <config.json> [-o out.png] [--spp N] [--p-rr X] [--lsn N] [--seed S] [--width W] [--height H]\n"
-                             "       [--eye x y z] [--lookat x y z] [--up x y z] [--reference | --exact | --fast] [--base-dir DIR] [--device N]\n"
+                             "       [--eye x y z] [--lookat x y z] [--up x y z] [--reference | --exact | --fast] [--bounded-radiance] [--base-dir DIR] [--device N]\n"
                              "       [--gpus N | --devices a,b,...] [--gather auto|rccl|copy]\n", argv[0]);
         return 2;
     }
@@ -32,7 +32,7 @@ int main(int argc, char** argv)
         std::string out = "out.png", base_dir = ".";
         uint64_t seed = 0;
         int device = 0;
-        bool reference = false, exact = false, fast = false;
+        bool reference = false, exact = false, fast = false, bounded = false;
         std::vector<int> devices;
         uint32_t gather = CRT_GATHER_AUTO;
         auto need = [&](int i, int n) { if (i + n >= argc) throw crt::Error(CRT_ERR_INVALID_ARG, std::string("missing value after ") + argv[i]); };
@@ -72,6 +72,7 @@ int main(int argc, char** argv)
             else if (a == "--reference") reference = true;
             else if (a == "--exact") exact = true;
             else if (a == "--fast") fast = true;
+            else if (a == "--bounded-radiance") bounded = true; // CRT_FLAG_BOUNDED_RADIANCE: a ring of samples instead of one radiance per path
             else if (a == "--eye" || a == "--lookat" || a == "--up") {
                 need(i, 3);
                 float* dst = a == "--eye" ? task.eye_pos : (a == "--lookat" ? task.lookat : task.up);
@@ -89,6 +90,7 @@ int main(int argc, char** argv)
         crt::Render& render = render_one_or_many;
         render.set_seed(seed);
         render.set_traversal(reference ? CRT_TRAVERSAL_REFERENCE : (fast && !exact) ? CRT_TRAVERSAL_FAST : CRT_TRAVERSAL_EXACT);
+        if (bounded) render.set_flags(CRT_FLAG_BOUNDED_RADIANCE);
         float inv_view[9];
         crt::get_inverse_view_matrix(task.eye_pos, task.lookat, task.up, inv_view);
         float fov_y = task.fov_y * (float)M_PI / 180; // src/main.cu:278

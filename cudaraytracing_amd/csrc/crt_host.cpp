@@ -651,7 +651,7 @@ void Render::run_view(const float eye_pos[3], const float inv_view_mat[9], float
     std::memset(&p, 0, sizeof(p));
     p.width = scene_->get_width(); p.height = scene_->get_height();
     p.spp = spp_; p.p_rr = P_RR_; p.light_sample_n = (int32_t)light_sample_n_;
-    p.seed = seed_; p.rank = 0; p.world = 1; p.traversal = traversal_; p.flags = 0;
+    p.seed = seed_; p.rank = 0; p.world = 1; p.traversal = traversal_; p.flags = flags_ & (CRT_FLAG_TRACE_ALL | CRT_FLAG_BOUNDED_RADIANCE);
     int rc;
     if (multi_) {
         rc = crt_multi_render(multi_, &cam, &p, frame_buffer_.data(), mean_buffer_.data(), rank_stats_.data(), &multi_info_);

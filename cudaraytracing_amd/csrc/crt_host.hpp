@@ -221,6 +221,7 @@ public:
     void set_light_sample_n(const int& n) { light_sample_n_ = (unsigned)n; }
     void set_seed(uint64_t s) { seed_ = s; }
     void set_traversal(uint32_t t) { traversal_ = t; }
+    void set_flags(uint32_t f) { flags_ = f; } // CRT_FLAG_* of crt_params that a caller may choose: CRT_FLAG_TRACE_ALL, CRT_FLAG_BOUNDED_RADIANCE
     void set_width(const unsigned& w);
     void set_height(const unsigned& h);
     const crt_stats& last_stats() const { return stats_; }
@@ -234,6 +235,7 @@ private:
     float P_RR_;
     uint64_t seed_ = 0;
     uint32_t traversal_ = CRT_TRAVERSAL_EXACT;
+    uint32_t flags_ = 0;
     crt_scene* device_scene_ = nullptr;
     crt_multi* multi_ = nullptr;
     crt_multi_info multi_info_{};

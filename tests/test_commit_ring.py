@@ -129,3 +129,21 @@ def test_a_shard_of_the_frame_through_the_ring():
         if old is not None:
             os.environ["CRT_COMMIT_RING_LOG2"] = old
         r.free()
+
+
+def test_cli_flag_for_the_ring(tmp_path):
+    """crt_cli --bounded-radiance (crt::Render::set_flags): the same PNG as without it (320 samples: more than the 256-sample ring a
+    160 x 120 frame gets, so the ring is really used)."""
+    import subprocess
+    from PIL import Image
+    from cudaraytracing_amd import build as b
+    cli = b.build_cli()
+    cfg = util.SCENES["cornell-box"]
+    outs = []
+    for extra in ([], ["--bounded-radiance"]):
+        out = str(tmp_path / ("c%d.png" % len(extra)))
+        r = subprocess.run([cli, cfg, "-o", out, "--spp", "320", "--width", "160", "--height", "120", "--seed", "7", "--base-dir", util.ROOT] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.asarray(Image.open(out)).copy())
+    assert np.array_equal(outs[0], outs[1]) and outs[0].std() > 10
