@@ -147,3 +147,26 @@ def test_cli_flag_for_the_ring(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(np.asarray(Image.open(out)).copy())
     assert np.array_equal(outs[0], outs[1]) and outs[0].std() > 10
+
+
+def test_ring_under_the_multi_device_entry():
+    """crt_multi_render with three ranks on the one device and CRT_FLAG_BOUNDED_RADIANCE passed through: every rank's scene handle
+    renders its shard with its own ring (ranks sharing a device never wait for one another: a commit only needs work that resident
+    waves of the same launch already hold); the gathered frame is the single-device frame."""
+    name, w, h, spp = "cornell-box", 120, 88, 300
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    ref = _render(name, w, h, spp)
+    m = crt.MultiRender(util.host_scene(name), spp, t.P_RR, t.light_sample_n, devices=[0, 0, 0], gather=crt.GATHER_COPY)
+    old = os.environ.pop("CRT_COMMIT_RING_LOG2", None)
+    os.environ["CRT_COMMIT_RING_LOG2"] = "3"   # (a share of 3 520 pixel slots would get a ring longer than the 300 samples: 8 samples forced)
+    try:
+        m.extra_flags = crt.FLAG_BOUNDED_RADIANCE
+        got = m.run_view(eye, iv, fov, width=w, height=h)
+        assert np.array_equal(got, ref[0]) and np.array_equal(util.bits(m.mean_buffer), util.bits(ref[1]))
+        assert m.info["paths"] == w * h * spp
+    finally:
+        os.environ.pop("CRT_COMMIT_RING_LOG2", None)
+        if old is not None:
+            os.environ["CRT_COMMIT_RING_LOG2"] = old
+        m.free()
