@@ -13,7 +13,7 @@ a = ap.parse_args()
 
 
 def render(scene, w, h, spp, env):
-    for k in ("CRT_COMMIT_RING_LOG2", "CRT_UNUSED_", "CRT_ITEM_ORDER"):
+    for k in ("CRT_COMMIT_RING_LOG2", "CRT_ITEM_ORDER"):
         os.environ.pop(k, None)
     os.environ.update({k: v for k, v in env.items() if k.startswith("CRT_")})
     t = crt.Task(os.path.join(ROOT, "scenes", scene, "config.json"), base_dir=ROOT)
