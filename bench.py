@@ -332,6 +332,15 @@ def main_rank(args):
             untraced_local = st.get("rays_untraced", 0)
         barrier()
         elapsed = time.perf_counter() - t0
+    # device memory of the per-path radiance of the timed frames on this rank (crt_radiance_storage): one 16-byte value per path of a
+    # chunk by default; CRT_FLAG_BOUNDED_RADIANCE would make it a ring of samples
+    radiance_storage = None
+    if not multi:
+        try:
+            rb, rr = render.radiance_storage()
+            radiance_storage = {"bytes": rb, "ring_samples": rr}
+        except Exception:
+            radiance_storage = None
     red_dev = torch.device("cpu") if one_device else device
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     r = torch.tensor([float(rays_local)], dtype=torch.float64, device=red_dev)
@@ -575,6 +584,7 @@ def main_rank(args):
                            "launched_by": "torch.distributed.run" if (world > 1 and not os.environ.get("CRT_BENCH_SPAWNED")) else
                                           ("bench.py (self-started ranks)" if world > 1 else "single process")},
             "build_flags": B.built_flags(),
+            "radiance_storage": radiance_storage,
             "scene_setup": setup,
             "rays_untraced_per_frame_rank0": int(untraced_local),
             "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
