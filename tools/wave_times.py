@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Per-wave times of k_mega3 launches (s_memrealtime at a wave's start, at the start of its last path, at its first exhausted cursor
+and at its end): where the end of a launch goes.  Needs a DIAGNOSTIC build of the library: apply
+tools/wave_times.patch (the kernel then writes four words per wave into a buffer whose address travels in MParams3::dbg_loads /
+dbg_valu, the host dumps it to $CRT_WAVE_TIMES after every launch), build it with tools/ab_build.sh and point CRT_LIB_PATH at it:
+    git apply tools/wave_times.patch && tools/ab_build.sh wt && git checkout cudaraytracing_amd/csrc/crt_kernels.hip
+    CRT_LIB_PATH=$PWD/cudaraytracing_amd/lib/ab/wt.so CRT_WAVE_TIMES=/tmp/wt.bin python3 tools/wave_times.py"""
 import os, sys, json, numpy as np
 ROOT='/root/repo' if os.path.isdir('/root/repo/tools') else os.getcwd()
 sys.path.insert(0, ROOT)
