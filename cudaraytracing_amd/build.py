@@ -103,15 +103,37 @@ class _BuildLock:
         self.f.close()
 
 
+def _compile_one(src, obj, verbose):
+    cmd = [HIPCC] + COMMON + DEVICE + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def build_lib(force=False, verbose=False):
+    """One object per translation unit under lib/obj/ (compiled in parallel, only the stale ones), then the link."""
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not _stale(LIB, LIB_DEPS, check_flags=True):
         return LIB
     with _BuildLock():
         if not force and not _stale(LIB, LIB_DEPS, check_flags=True):  # another process has built it meanwhile
             return LIB
+        from concurrent.futures import ThreadPoolExecutor
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        flags_changed = force or built_flags() != flags_string()
+        headers = [d for d in LIB_DEPS if d not in LIB_SOURCES]
+        jobs, objs = [], []
+        for s in LIB_SOURCES:
+            obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+            objs.append(obj)
+            if flags_changed or _stale(obj, [s] + headers):
+                jobs.append((s, obj))
+        with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+            for f in [ex.submit(_compile_one, s, o, verbose) for s, o in jobs]:
+                f.result()
         tmp = LIB + ".tmp.%d" % os.getpid()
-        cmd = [HIPCC] + COMMON + DEVICE + ["-shared"] + [os.path.join(CSRC, s) for s in LIB_SOURCES] + ["-ldl", "-lpthread", "-o", tmp]
+        cmd = [HIPCC] + DEVICE + ["-shared", "-fPIC"] + objs + ["-ldl", "-lpthread", "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
