@@ -62,6 +62,7 @@ struct DevScene {
     int32_t root4;           // root of the 4-wide tree (a leaf ref if the scene is a single leaf)
     float coord_max;         // largest |coordinate| of a box of the 4-wide tree, +inf if one is not finite (start_ray: which rays may walk it)
     const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
+    uint32_t empty4_off;     // byte offset in nodes4 of a node of four empty slots, behind the tree (the decoupled-leaves step parks idle lanes there)
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

@@ -1160,6 +1160,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 template <bool R16_>
 struct Pool3LdsT {
     static constexpr bool R16 = R16_;
+    static constexpr bool DEC = false;
+    static constexpr int P = POOL3_P, QCAP = POOL3_QCAP;
     static constexpr int LV = R16_ ? 2 * POOL_LV : POOL_LV;
     typedef typename std::conditional<R16_, short, int>::type stk_t;
     float4 A[POOL3_P];           // origin.xyz, T = distance to the light (any-hit rays) | best hit distance (closest-hit rays)
@@ -1169,10 +1171,56 @@ struct Pool3LdsT {
     uint32_t D[POOL3_P];         // stack depth | leaf offset << 8 | RF_* flags
     uint8_t ring[PH3_N + 1][POOL3_QCAP];
     uint32_t waitq;              // ring PH3_WAIT: entries | head << 8 | tail << 16 (kept here, not in scalar registers: only the LC phase uses it)
+    __device__ __forceinline__ uint8_t* rq(const int p) { return ring[p]; }
 };
 typedef Pool3LdsT<false> Pool3Lds;
 static_assert(sizeof(Pool3LdsT<true>) == sizeof(Pool3Lds), "16-bit stack entries: twice the levels in the same bytes");
 static_assert(sizeof(Pool3Lds) * 4 * CRT_WAVES <= 160 * 1024, "the pool does not fit CRT_WAVES waves per SIMD into 160 KiB of LDS");
+
+// ---- decoupled leaves (DEC): the pool of the kernels whose leaf tests are work items of their own ----
+// A ray walks the INNER nodes only.  Every leaf child whose box it hits becomes an entry (ray, leaf record) of the wave's leaf queue,
+// and the ray goes on at once; the leaf step takes 64 entries -- always a full batch -- tests the record's triangles against the
+// entry's ray and folds an accepted hit into the ray's record with one LDS atomic minimum over (distance, ~triangle), which is the
+// reference's own tie rule (crt_trace.h: among equal distances the largest leaf start wins; inside a leaf the first triangle, which
+// the step resolves in registers), so the order in which a ray's leaves are tested cannot matter.  The record counts its entries in
+// flight; the ray is finished when its stack is empty and that count is zero, and whichever step sees that routes it.  What it buys:
+// the leaf step has no stack, no node, no ring push (it was as long as the arithmetic it carries), its batches are full, a ray
+// leaves the inner ring once instead of once per leaf, and the stack holds inner nodes only -- six 16-bit levels cover scenes of
+// 32 768 four-wide nodes whatever the number of leaves (24-bit leaf refs travel in the queue entries).
+#ifndef LEAFQ_CAP
+#define LEAFQ_CAP 256 /* entries of the leaf queue, a power of two; an inner batch is cut to (free entries) / 4 rays */
+#endif
+static_assert((LEAFQ_CAP & (LEAFQ_CAP - 1)) == 0 && LEAFQ_CAP >= 128, "leaf queue: a power of two, room for half a batch of inner steps");
+#define RD_PEND_SHIFT 8
+#define RD_PEND_MASK 0x3ff00u  /* word D, bits 8-17: leaf-queue entries of the ray that have not been tested yet */
+#define RD_FIN 0x8000000u      /* word D: the traversal of the inner nodes is over */
+#define LEAF_REC_MAX 0x7fffffu /* a queue entry is ray | leaf record << 8, and a node's row [7] keeps the sign bit for "leaf" */
+template <bool R16_, bool RING_>
+struct Pool4LdsT {
+    static constexpr bool R16 = R16_;
+    static constexpr bool DEC = true;
+#ifdef POOL4_P
+    static constexpr int P = POOL4_P;
+#else
+    static constexpr int P = RING_ ? 148 : 152;
+#endif
+    static constexpr int QCAP = (P + 3) & ~3;
+    static constexpr int LV = R16_ ? 6 : 3;
+    typedef typename std::conditional<R16_, short, int>::type stk_t;
+    float4 A[P];                 // origin.xyz, the distance an accepted hit must stay below by more than EPSILON: the light's for an any-hit ray, +inf otherwise
+    float4 B[P];                 // direction.xyz, bits(current node ref)
+    unsigned long long best[P];  // the ray's answer so far: bits(distance) << 32 | ~triangle; FLT_MAX << 32 | 0 = nothing
+    stk_t stk[LV][P];            // traversal stack (inner nodes only); deeper levels spill to global memory
+    uint32_t D[P];               // stack depth (bits 0-7) | entries in flight (RD_PEND_MASK) | RF_* flags, RD_FIN
+    uint32_t leafq[LEAFQ_CAP];
+    uint8_t ring[(RING_ ? 5 : 4)][QCAP]; // INNER, LA, LB, LC (, WAIT)
+    uint32_t waitq;
+    __device__ __forceinline__ uint8_t* rq(const int p) { return ring[p == PH3_INNER ? 0 : p - 1]; }
+};
+static_assert(sizeof(Pool4LdsT<true, false>) * 4 * CRT_WAVES <= 160 * 1024 && sizeof(Pool4LdsT<true, true>) * 4 * CRT_WAVES <= 160 * 1024 &&
+              sizeof(Pool4LdsT<false, false>) * 4 * CRT_WAVES <= 160 * 1024 && sizeof(Pool4LdsT<false, true>) * 4 * CRT_WAVES <= 160 * 1024,
+              "the DEC pool does not fit CRT_WAVES waves per SIMD into 160 KiB of LDS");
+static_assert(Pool4LdsT<true, false>::P <= 256, "ray ids of a pool must fit a byte");
 
 struct MParams3 {
     MParams M;
@@ -1181,7 +1229,7 @@ struct MParams3 {
     int32_t dbg_loads, dbg_valu; // unused by the kernel; tools/bbprof passes the address of its counter buffer in these two dwords
 };
 
-static_assert(offsetof(MParams3, dbg_loads) == 652 && offsetof(MParams3, dbg_valu) == 656, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
+static_assert(offsetof(MParams3, dbg_loads) == 668 && offsetof(MParams3, dbg_valu) == 672, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
 
 struct NewRay {
     F3 o, d;
@@ -1244,8 +1292,9 @@ __device__ __forceinline__ int smax(const int a, const int b)
     return r;
 }
 
-// Ring index in [0, 2 * POOL3_QCAP) -> [0, POOL3_QCAP).
-__device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)POOL3_QCAP); }
+// Ring index in [0, 2 * QCAP) -> [0, QCAP).
+template <int QCAP>
+__device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)QCAP); }
 
 // Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
 // or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
@@ -1305,6 +1354,20 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
         // a NaN or -inf limit can never be "blocked"; +inf is blocked by any hit
         answered = !(nr.tl == nr.tl) || nr.tl == -pinf() || (nr.flags & RF_SKIP) != 0;
     }
+    if constexpr (LDS::DEC) {
+        static_assert(!LDS::DEC || MODE == 2, "decoupled leaves: CRT_TRAVERSAL_EXACT");
+        // (a scene that is one leaf has no inner node to start at: its rays take the reference-arithmetic arm, which hands leaf refs
+        // to the queue one by one)
+        if (ref < 0) flags |= RF_EXACT;
+        S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, (flags & RF_ANYHIT) ? T : pinf());
+        S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(ref));
+        S.best[id] = (unsigned long long)0x7f7fffffu << 32; // (FLT_MAX, no triangle)
+        S.D[id] = flags;
+        enters_exact = false;
+        if (answered) return route_done<QUERY>(flags);
+        enters_exact = (flags & RF_EXACT) != 0;
+        return PH3_INNER;
+    } else {
     S.A[id] = make_float4(nr.o.x, nr.o.y, nr.o.z, T);
     S.B[id] = make_float4(nr.d.x, nr.d.y, nr.d.z, __int_as_float(-1));
     S.node[id] = ref;
@@ -1313,6 +1376,27 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     if (answered) return route_done<QUERY>(flags);
     enters_exact = MODE != 1 && (flags & RF_EXACT) != 0; // (counted by the caller: the traversal steps of a pool without such rays skip their handling)
     return ref >= 0 ? PH3_INNER : PH3_LEAF;
+    }
+}
+
+// DEC: the answer of a finished ray as the logic phases read it from the non-DEC record (A.w = distance, B.w = triangle)
+template <class LDS>
+__device__ __forceinline__ void ray_result(LDS& S, const uint32_t id, float4& qa, float4& qb)
+{
+    qa = S.A[id]; qb = S.B[id];
+    if constexpr (LDS::DEC) {
+        const unsigned long long b = S.best[id];
+        qa.w = __uint_as_float((uint32_t)(b >> 32));
+        qb.w = __uint_as_float(~(uint32_t)b);
+    }
+}
+// DEC: where a complete ray goes (route_done); a closest-hit ray that has found a surface goes to LA instead of LC
+template <bool QUERY>
+__device__ __forceinline__ uint32_t route_complete(const uint32_t rec_flags, const bool has_hit)
+{
+    if (QUERY) return PH3_LC;
+    const uint32_t r = (rec_flags >> RR_ROUTE_SHIFT) & 3u;
+    return (has_hit ? (r & 1u) : r) + (uint32_t)PH3_LA;
 }
 
 // Visibility of a next-event sample (Render.cuh:19-27, :272): tl - hit.t > EPSILON with hit.t = FLT_MAX when nothing was
@@ -1860,6 +1944,82 @@ __device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MP
     return stack_pop_ahead(S, M, id, g, sp, ref, top, LV); // (no child was hit: nothing was pushed, the top is the one read above)
 }
 
+// The same step with the leaves decoupled (DEC): a leaf child that is hit becomes an entry (ray | leaf record << 8) of the wave's leaf
+// queue -- appended right here, child by child, at tail + number of lanes below with an entry of the same child; `added` counts the
+// entries of the batch -- and takes no part in the ordering; among the inner children the nearest is next, the others are pushed.
+// Row [7] of a node holds the refs in the form this needs: an inner child as in row [6], a leaf child as 0x80000000 | record << 8.
+// The ray's count of entries in flight (word D) grows by LDS atomics, one per entry.  CRT_TRAVERSAL_EXACT only (no bound).
+// Runs inside the divergent region of the batch's lanes: ballots see those lanes only; lq_t is the queue's tail before the batch.
+template <class LDS>
+__device__ __forceinline__ void leafq_push(LDS& S, const uint32_t id, const bool hit, const unsigned long long m, const uint32_t entry, const uint32_t lq_t, uint32_t& added)
+{
+    // m = the ballot of `hit`, formed by the caller from the ballots of its compares (a ballot of their conjunction would cost a
+    // select and another compare)
+    if (m) {
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, lq_t + added));
+        if (hit) {
+            S.leafq[slot & (uint32_t)(LEAFQ_CAP - 1)] = entry;
+            __hip_atomic_fetch_add(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        added += (uint32_t)__popcll(m);
+    }
+}
+template <bool STATS, class LDS>
+__device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+                                                int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
+                                                const bool enable)
+{
+    // (every lane of the batch runs the step, so that the appends -- ballots, the running count `added` -- stay wave-uniform; a lane
+    // without `enable`, an any-hit ray that has its answer or a ray of the reference-arithmetic path, steps at the EMPTY node the host
+    // puts behind the tree -- four inverted boxes: nothing is hit, appended or pushed)
+    const char* nb = (const char*)sc.nodes4;
+    const uint32_t noff = enable ? (uint32_t)ref * 128u : sc.empty4_off;
+    const uint32_t ox = noff + ((__float_as_uint(inv.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv.y) >> 27) & 16u),
+                   oz = noff + ((__float_as_uint(inv.z) >> 27) & 16u);
+    const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
+    const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
+    const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
+    const float4 rf = *(const float4*)((nb + noff) + 112);
+    const int top = stack_top_ahead(S, id, sp, LDS::LV);
+    if (STATS && enable) tc.inner++;
+    float t0, t1, t2, t3;
+    slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    const float inf = pinf();
+    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    const bool l0 = (t0 < inf) & (r0 < 0), l1 = (t1 < inf) & (r1 < 0), l2 = (t2 < inf) & (r2 < 0), l3 = (t3 < inf) & (r3 < 0);
+#define CRT_LEAF_MASK(t_, r_) (__builtin_amdgcn_ballot_w64(t_ < inf) & __builtin_amdgcn_ballot_w64(r_ < 0))
+    leafq_push(S, id, l0, CRT_LEAF_MASK(t0, r0), ((uint32_t)r0 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l1, CRT_LEAF_MASK(t1, r1), ((uint32_t)r1 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l2, CRT_LEAF_MASK(t2, r2), ((uint32_t)r2 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l3, CRT_LEAF_MASK(t3, r3), ((uint32_t)r3 & 0x7fffff00u) | id, lq_t, added);
+#undef CRT_LEAF_MASK
+    any_leaf = l0 | l1 | l2 | l3;
+    t0 = r0 < 0 ? inf : t0; t1 = r1 < 0 ? inf : t1; t2 = r2 < 0 ? inf : t2; t3 = r3 < 0 ? inf : t3;
+#define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
+#ifndef CRT_DEC_UNSORTED
+    CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2)
+#endif
+#undef CRT_CE
+    const bool c0 = t0 < inf, c1 = t1 < inf, c2 = t2 < inf, c3 = t3 < inf;
+    const int l3_ = sp, l2_ = l3_ + (c3 ? 1 : 0), l1_ = l2_ + (c2 ? 1 : 0);
+    constexpr int LV = LDS::LV;
+    typedef typename LDS::stk_t stk_t;
+    if (c3 & (l3_ < LV)) S.stk[l3_][id] = (stk_t)r3;
+    if (c2 & (l2_ < LV)) S.stk[l2_][id] = (stk_t)r2;
+    if (c1 & (l1_ < LV)) S.stk[l1_][id] = (stk_t)r1;
+    const int sp_new = l1_ + (c1 ? 1 : 0);
+    if (__builtin_amdgcn_ballot_w64((sp_new > l3_) & (sp_new > LV))) {
+        if (c3 & (l3_ >= LV)) M.spill[(size_t)(l3_ - LV) * M.M.spill_stride + g] = r3;
+        if (c2 & (l2_ >= LV)) M.spill[(size_t)(l2_ - LV) * M.M.spill_stride + g] = r2;
+        if (c1 & (l1_ >= LV)) M.spill[(size_t)(l1_ - LV) * M.M.spill_stride + g] = r1;
+    }
+    sp = sp_new;
+    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    if (c0) { ref = r0; return false; }
+    return stack_pop_ahead(S, M, id, g, sp, ref, top, LV);
+}
+
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
 // visit order, no pruning) or, for the handful of FAST rays with non-finite operands, reference arithmetic on that topology
 // with ordering and pruning.  d = direction (the sign selects the near plane, DeviceBVH.cuh:101-119).
@@ -1902,19 +2062,21 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 // are not mixed with it
 // RING: the commit ring (in-order sum of the samples inside the launch, see ring_publish) -- its own instantiations: the kernels
 // without it are, instruction for instruction, what they were before it existed
-template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false, bool RING = false>
+template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false, bool RING = false, bool DEC = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, CRT_WAVES))) void k_mega3(const MParams3 M3)
 {
     static_assert(!(RING && (QUERY || STATS)), "the commit ring is a render without counters");
     static_assert(!(R16 && MODE == 1), "CRT_TRAVERSAL_REFERENCE walks the 2-wide trees: 32-bit stack entries");
-    typedef Pool3LdsT<R16> LDS3;
+    static_assert(!DEC || MODE == 2, "decoupled leaves: CRT_TRAVERSAL_EXACT");
+    typedef typename std::conditional<DEC, Pool4LdsT<R16, RING>, Pool3LdsT<R16>>::type LDS3;
     __shared__ LDS3 S;
+    constexpr int QCAP = LDS3::QCAP;
     const MParams& M = M3.M;
     const LParams& P = M.P;
     const DevScene& sc = P.sc; // (one copy of the scene pointers in scalar registers: the logic phases use P.sc too)
     const Pool& pl = P.pool;
     const int lane = threadIdx.x;
-    const uint32_t base = blockIdx.x * (uint32_t)POOL3_P; // first global slot of this wave's pool
+    const uint32_t base = blockIdx.x * (uint32_t)LDS3::P; // first global slot of this wave's pool
     Tables<false> tb;
     tb.mats = sc.mats; tb.lights = sc.lights;
 
@@ -1926,20 +2088,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     int n_exact = 0; // rays on the reference-arithmetic path (RF_EXACT) that are in the traversal phases of this pool
 
     // ring state: wave-uniform scalars
-    int qn[PH3_N], qh[PH3_N], qt[PH3_N]; // entries, head, tail (head and tail in [0, POOL3_QCAP))
+    int qn[PH3_N], qh[PH3_N], qt[PH3_N]; // entries, head, tail (head and tail in [0, QCAP))
 #pragma unroll
     for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; qt[p] = 0; }
+    uint32_t dg_b[5] = {0, 0, 0, 0, 0}, dg_l[5] = {0, 0, 0, 0, 0}; // STATS: batches and rays per phase
+    uint32_t lq_h = 0, lq_t = 0; // DEC: the leaf queue's head and tail, free-running (entries = tail - head, index = counter mod LEAFQ_CAP)
     constexpr bool commit_ring = RING;
     if (commit_ring && lane == 0) S.waitq = 0u;
     // every ray of the pool starts in LC with a path in stage NEW
     {
-        const int n_valid = (int)min((uint32_t)POOL3_P, pl.n > base ? pl.n - base : 0u);
+        const int n_valid = (int)min((uint32_t)LDS3::P, pl.n > base ? pl.n - base : 0u);
         for (int i = lane; i < n_valid; i += 64) {
-            S.ring[PH3_LC][i] = (uint8_t)i;
+            S.rq(PH3_LC)[i] = (uint8_t)i;
             pl.la[base + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_NEW << 8));
         }
         qn[PH3_LC] = n_valid;
-        qt[PH3_LC] = n_valid >= POOL3_QCAP ? n_valid - POOL3_QCAP : n_valid;
+        qt[PH3_LC] = n_valid >= QCAP ? n_valid - QCAP : n_valid;
     }
 
 // appends the processed rays (lane active = `on`, ray `id`) to the ring of their new phase
@@ -1950,11 +2114,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         if (m) {                                                                                                           \
             /* slot = tail + number of lanes below this one that go the same way: the tail rides in as mbcnt's addend */      \
             const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qt[p])); \
-            if (mine) S.ring[p][ring_wrap(slot)] = (uint8_t)id;                                                            \
+            if (mine) S.rq(p)[ring_wrap<QCAP>(slot)] = (uint8_t)id;                                                            \
             const int add = (int)__popcll(m);                                                                              \
             qn[p] += add;                                                                                                  \
             qt[p] += add;                                                                                                  \
-            if (qt[p] >= POOL3_QCAP) qt[p] -= POOL3_QCAP;                                                                  \
+            if (qt[p] >= QCAP) qt[p] -= QCAP;                                                                  \
         }                                                                                                                  \
     }
 // after a traversal step: a ray goes on to an inner node or a leaf, or it is finished -- only then (one wave-uniform test
@@ -1963,10 +2127,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 // takes the (up to) 64 oldest rays of ring p
 #define POP3(p)                                                                                                            \
     const int take = min(64, qn[p]);                                                                                       \
+    if (STATS) { dg_b[p]++; dg_l[p] += (uint32_t)take; }                                                                   \
     const bool on = lane < take;                                                                                           \
-    const uint32_t id = S.ring[p][ring_wrap((uint32_t)(qh[p] + lane))];                                                    \
+    const uint32_t id = S.rq(p)[ring_wrap<QCAP>((uint32_t)(qh[p] + lane))];                                                    \
     qh[p] += take;                                                                                                         \
-    if (qh[p] >= POOL3_QCAP) qh[p] -= POOL3_QCAP;                                                                          \
+    if (qh[p] >= QCAP) qh[p] -= QCAP;                                                                          \
     qn[p] -= take;                                                                                                         \
     const uint32_t g = base + id;                                                                                          \
     uint32_t nph = PH3_NONE;
@@ -1999,10 +2164,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         {
             // key = batch size * 8 + phase number (the phase numbers are the tie-break order)
             const int kC = min(qn[PH3_LC], 64) * 8 + PH3_LC, kA = min(qn[PH3_LA], 64) * 8 + PH3_LA, kB = min(qn[PH3_LB], 64) * 8 + PH3_LB;
-            const int kL = min(qn[PH3_LEAF], 64) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
+            // (DEC: the leaf queue counts entries, not rays; with 64 or more it is the fullest there can be and wins over the inner ring,
+            // so an inner batch always finds room for 4 entries per ray of at least 48 rays)
+            const int kL = min(DEC ? (int)(lq_t - lq_h) : qn[PH3_LEAF], 64) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
             // (s_max_i32 by hand: the compiler folds nested maxima of wave-uniform values into v_max3_i32 -- a vector instruction, plus
             // two moves in and a v_readfirstlane back)
-            const int best = smax(smax(smax(kC, kA), smax(kB, kL)), kI);
+            const int best = STATS ? max(max(max(kC, kA), max(kB, kL)), kI) // (the counting kernels keep more scalars: theirs may live in vector registers)
+                                   : smax(smax(smax(kC, kA), smax(kB, kL)), kI);
             act = best < 8 ? PH3_NONE : (best & 7); // (best < 8: every ray of the pool is dead)
         }
         if (act > PH3_LEAF) break;
@@ -2011,6 +2179,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         // (a wave-uniform scalar): while it is zero -- practically always -- the steps run in the form that has none of that handling.
         auto inner_arm = [&](auto may_exact_) __attribute__((always_inline)) {
             constexpr bool MAY_EXACT = decltype(may_exact_)::value;
+            if constexpr (!DEC) {
             // ---- inner-node step: the child boxes, nearest child next, the other hit children pushed ----
             POP3(PH3_INNER)
             bool t_done = false;
@@ -2049,9 +2218,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             if (MAY_EXACT && MODE != 1) n_exact -= (int)__popcll(__ballot(on && t_done && (t_flags & RF_EXACT) != 0));
             PUSH_TRAV()
+            }
         };
         auto leaf_arm = [&](auto may_exact_) __attribute__((always_inline)) {
             constexpr bool MAY_EXACT = decltype(may_exact_)::value;
+            if constexpr (!DEC) {
             // ---- leaf step: the record's two triangles in one packed computation ----
             POP3(PH3_LEAF)
             bool t_done = false;
@@ -2111,8 +2282,177 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             if (MAY_EXACT && MODE != 1) n_exact -= (int)__popcll(__ballot(on && t_done && (t_flags & RF_EXACT) != 0));
             PUSH_TRAV()
+            }
         };
+        // ---- DEC arms (Pool4LdsT): see there ----
+// appends the lanes with `cond_` (ray `id`) to ring p_
+#define PUSH_ONE(p_, cond_)                                                                                                \
+    {                                                                                                                      \
+        const bool mine_ = (cond_);                                                                                        \
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(mine_);                                                  \
+        if (m_) {                                                                                                          \
+            const uint32_t slot_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, (uint32_t)qt[p_])); \
+            if (mine_) S.rq(p_)[ring_wrap<QCAP>(slot_)] = (uint8_t)id;                                                     \
+            const int add_ = (int)__popcll(m_);                                                                            \
+            qn[p_] += add_;                                                                                                \
+            qt[p_] += add_;                                                                                                \
+            if (qt[p_] >= QCAP) qt[p_] -= QCAP;                                                                            \
+        }                                                                                                                  \
+    }
+        auto inner_arm_dec = [&](auto may_exact_) __attribute__((always_inline)) {
+            constexpr bool MAY_EXACT = decltype(may_exact_)::value;
+            if constexpr (DEC) {
+            // ---- inner-node step: the child boxes; leaf children that are hit -> queue entries; nearest inner child next ----
+            // The whole step, the appends to the leaf queue and to the inner ring included, runs under the mask of the batch's lanes
+            // (a ballot there sees those lanes only); what the appends add to the wave-uniform cursors comes out of the region in a
+            // vector register of lane 0, which is always one of them.
+            const int room = (int)((uint32_t)LEAFQ_CAP - (lq_t - lq_h)) >> 2;
+            const int take = min(min(64, qn[PH3_INNER]), room);
+            if (STATS) { dg_b[PH3_INNER]++; dg_l[PH3_INNER] += (uint32_t)take; }
+            const bool on = lane < take;
+            const uint32_t id = S.rq(PH3_INNER)[ring_wrap<QCAP>((uint32_t)(qh[PH3_INNER] + lane))];
+            qh[PH3_INNER] += take;
+            if (qh[PH3_INNER] >= QCAP) qh[PH3_INNER] -= QCAP;
+            qn[PH3_INNER] -= take;
+            const uint32_t g = base + id;
+            uint32_t xfer = 0;            // entries appended to the leaf queue | rays re-queued << 16 | rays of the reference-arithmetic path that ended << 24
+            uint32_t nph = PH3_NONE;      // a ray that is complete (its walk is over and none of its entries is in flight): where it goes
+            if (on) {
+                const float4 qa = S.A[id], qb = S.B[id];
+                const uint32_t qd = S.D[id];
+                const uint32_t blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int ref = __float_as_int(qb.w);
+                const F3 o = f3(qa.x, qa.y, qa.z), inv = inv3_exact(f3(qb.x, qb.y, qb.z));
+                int sp = (int)(qd & 0xffu);
+                // an any-hit ray that has its answer looks no further (entries of it still in the queue are tested and change nothing)
+                bool done = (qd & RF_ANYHIT) != 0 && blo != 0u;
+                const bool go = !done;
+                const bool ex = MAY_EXACT && (qd & RF_EXACT) != 0;
+                uint32_t added = 0;
+                bool any_leaf = false;
+                {
+                    // (a lane that does not take the step -- see inner4_step_dec -- keeps its node, depth and `done`)
+                    const bool en = go && !ex;
+                    int ref4 = ref, sp4 = sp;
+                    const bool done4 = inner4_step_dec<STATS>(sc, S, M3, id, g, o, inv, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, en);
+                    if (en) { ref = ref4; sp = sp4; done = done4; }
+                }
+                if (MAY_EXACT) {
+                    if (__builtin_amdgcn_ballot_w64(go && ex)) { // reference arithmetic on the reference topology, one thing per visit:
+                        const bool lf = go && ex && ref < 0;     // a leaf ref becomes a queue entry, an inner node is stepped
+                        leafq_push(S, id, lf, __builtin_amdgcn_ballot_w64(lf), ((uint32_t)~ref << 8) | id, lq_t, added);
+                        if (go && ex) {
+                            if (lf) {
+                                any_leaf = true;
+                                done = stack_pop(S, M3, id, g, sp, ref, lds_levels<LDS3>(true));
+                            } else {
+                                done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), pinf(), ref, sp, tc, max_sp);
+                            }
+                        }
+                    }
+                }
+                // the record: node, stack depth, "the walk is over" -- the count of entries in flight in between is touched by atomics only
+                // (leafq_push above: those additions are in LDS before this one, same wave, in order)
+                S.B[id].w = __int_as_float(ref);
+                __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (done ? RD_FIN : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool comp = done & !any_leaf & ((qd & RD_PEND_MASK) == 0u);
+                if (STATS && comp && blo != 0u) tc.hits++;
+                if (__builtin_amdgcn_ballot_w64(comp)) nph = comp ? route_complete<QUERY>(qd, blo != 0u) : nph;
+                // re-queue the rays that go on
+                const unsigned long long mc = __builtin_amdgcn_ballot_w64(!done);
+                if (mc) {
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, (uint32_t)qt[PH3_INNER]));
+                    if (!done) S.rq(PH3_INNER)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
+                }
+                xfer = added | ((uint32_t)__popcll(mc) << 16);
+                if (MAY_EXACT) xfer |= (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(done && (qd & RF_EXACT) != 0)) << 24;
+            }
+            xfer = (uint32_t)__builtin_amdgcn_readfirstlane((int)xfer);
+            lq_t += xfer & 0xffffu;
+            {
+                const int c = (int)((xfer >> 16) & 0xffu);
+                qn[PH3_INNER] += c;
+                qt[PH3_INNER] += c;
+                if (qt[PH3_INNER] >= QCAP) qt[PH3_INNER] -= QCAP;
+            }
+            if (MAY_EXACT) n_exact -= (int)(xfer >> 24);
+            if (__builtin_amdgcn_ballot_w64(nph != PH3_NONE)) {
+                PUSH_ONE(PH3_LA, nph == PH3_LA) PUSH_ONE(PH3_LB, nph == PH3_LB) PUSH_ONE(PH3_LC, nph == PH3_LC)
+            }
+            }
+        };
+        auto leaf_arm_dec = [&]() __attribute__((always_inline)) {
+            if constexpr (DEC) {
+            // ---- leaf step: 64 entries of the queue, the record's two triangles in one packed computation ----
+            const int take = min(64, (int)(lq_t - lq_h));
+            if (STATS) { dg_b[PH3_LEAF]++; dg_l[PH3_LEAF] += (uint32_t)take; }
+            const bool on = lane < take;
+            const uint32_t item = S.leafq[(lq_h + (uint32_t)lane) & (uint32_t)(LEAFQ_CAP - 1)];
+            lq_h += (uint32_t)take;
+            const uint32_t id = item & 0xffu;
+            bool comp = false;
+            uint32_t t_flags = 0, blo = 0;
+            if (on) {
+                const float4 qa = S.A[id], qb = S.B[id];
+                const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
+                const float Tl = qa.w;
+                uint32_t rec = item >> 8;
+                // the leaf's candidate: the first of its triangles among equal distances (ascending index, strict <: DeviceBVH.cuh:34-41)
+                bool have = false;
+                float bt = 0.0f;
+                int bi = 0;
+                int left = 1;
+                for (int k = 0; left > 0; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
+                    const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
+                    const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
+                    const int it = __float_as_int(g4.z);
+                    if (k == 0) left = __float_as_int(g4.w);
+                    const bool two = left > 1;
+                    bool a0, a1;
+                    float t0, t1;
+                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
+                    if (STATS) { tc.tests += two ? 2u : 1u; }
+                    // (Tl - t > EPSILON: the visibility test of an any-hit ray, Render.cuh:19-27; always true for Tl = +inf and a finite t,
+                    // false for t = +inf, which the reference's t < best.t rejects as well)
+                    const bool b0 = a0 & (Tl - t0 > CRT_EPSILON);
+                    const bool b1 = a1 & two & (Tl - t1 > CRT_EPSILON);
+                    const bool s1 = b1 & (!b0 | (t1 < t0));
+                    const float ct = s1 ? t1 : t0;
+                    const int ci = s1 ? it + 1 : it;
+                    const bool up = (b0 | b1) & (!have | (ct < bt));
+                    bt = up ? ct : bt; bi = up ? ci : bi; have = have | up;
+                    left -= 2;
+                }
+                if (STATS) tc.leaf++;
+                // across leaves: the smaller distance, among equal ones the larger leaf start (crt_trace.h) = the larger triangle index, as
+                // the leaves own disjoint ascending ranges -- one 64-bit minimum over (bits(t), ~triangle); t > EPSILON > 0, so its bits order as it does
+                if (__builtin_amdgcn_ballot_w64(have)) {
+                    if (have) __hip_atomic_fetch_min(&S.best[id], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)(uint32_t)~bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const uint32_t od = __hip_atomic_fetch_sub(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                comp = (od & (RD_PEND_MASK | RD_FIN)) == ((1u << RD_PEND_SHIFT) | RD_FIN); // the last entry of a ray whose walk is over
+                t_flags = od;
+            }
+            if (__builtin_amdgcn_ballot_w64(comp)) {
+                if (comp) blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (STATS && comp && blo != 0u) tc.hits++;
+                const uint32_t nph = comp ? route_complete<QUERY>(t_flags, blo != 0u) : (uint32_t)PH3_NONE;
+                PUSH_ONE(PH3_LA, nph == PH3_LA) PUSH_ONE(PH3_LB, nph == PH3_LB) PUSH_ONE(PH3_LC, nph == PH3_LC)
+            }
+            }
+        };
+#undef PUSH_ONE
         const bool plain = MODE == 1 || n_exact == 0;
+        if constexpr (DEC) {
+            if (act == PH3_INNER) {
+                if (plain)
+                    inner_arm_dec(std::false_type{});
+                else
+                    inner_arm_dec(std::true_type{});
+            } else {
+                leaf_arm_dec();
+            }
+        } else {
         if (act == PH3_INNER) {
             if (plain)
                 inner_arm(std::false_type{});
@@ -2124,6 +2464,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             else
                 leaf_arm(std::true_type{});
         }
+        }
       }
         // (commit ring: a pool with nothing to do but slots that are held back looks at those)
         if (act == PH3_NONE && !(commit_ring && (__builtin_amdgcn_readfirstlane((int)S.waitq) & 0xff) != 0)) break;
@@ -2133,8 +2474,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_A<MODE, RING>(Pl, tl, g, S.A[id], S.B[id], nr, cnt, ALL);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                float4 ra_, rb_;
+                ray_result(S, id, ra_, rb_);
+                nph = logic_A<MODE, RING>(Pl, tl, g, ra_, rb_, nr, cnt, ALL);
+                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
@@ -2144,8 +2487,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                nph = logic_B<MODE, RING>(Pl, g, S.A[id], S.B[id], nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                float4 ra_, rb_;
+                ray_result(S, id, ra_, rb_);
+                nph = logic_B<MODE, RING>(Pl, g, ra_, rb_, nr);
+                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
@@ -2162,11 +2507,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             const int src_n = held ? wn : qn[PH3_LC], src_h = held ? wh : qh[PH3_LC];
             const int take = min(64, src_n);
+            if (STATS) { dg_b[PH3_LC]++; dg_l[PH3_LC] += (uint32_t)take; }
             const bool on = lane < take;
-            const uint32_t id = (held ? S.ring[PH3_WAIT] : S.ring[PH3_LC])[ring_wrap((uint32_t)(src_h + lane))];
+            const uint32_t id = (held ? S.rq(PH3_WAIT) : S.rq(PH3_LC))[ring_wrap<QCAP>((uint32_t)(src_h + lane))];
             {
                 int nh = src_h + take;
-                if (nh >= POOL3_QCAP) nh -= POOL3_QCAP;
+                if (nh >= QCAP) nh -= QCAP;
                 if (held) { wh = nh; wn -= take; } else { qh[PH3_LC] = nh; qn[PH3_LC] -= take; }
             }
             const uint32_t g = base + id;
@@ -2176,8 +2522,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             if (on) {
                 LOGIC_PARAMS()
                 NewRay nr;
-                const int got = QUERY ? (query_C(Pl, g, S.A[id], S.B[id], nr) ? LC_RAY : LC_DEAD) : logic_C<RING>(Pl, tl, g, cnt, nr, fin_key);
-                if (got == LC_RAY) nph = start_ray<MODE, QUERY>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                float4 ra_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb_ = ra_;
+                if (QUERY) ray_result(S, id, ra_, rb_);
+                const int got = QUERY ? (query_C(Pl, g, ra_, rb_, nr) ? LC_RAY : LC_DEAD) : logic_C<RING>(Pl, tl, g, cnt, nr, fin_key);
+                if (got == LC_RAY) nph = start_ray<MODE, QUERY, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
                 wait = got == LC_WAIT;
             }
             n_exact += (int)__popcll(__ballot(new_exact));
@@ -2188,11 +2536,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const unsigned long long mw = __ballot(wait);
                 if (mw) {
                     const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, (uint32_t)wt));
-                    if (wait) S.ring[PH3_WAIT][ring_wrap(slot)] = (uint8_t)id;
+                    if (wait) S.rq(PH3_WAIT)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
                     const int add = (int)__popcll(mw);
                     wn += add;
                     wt += add;
-                    if (wt >= POOL3_QCAP) wt -= POOL3_QCAP;
+                    if (wt >= QCAP) wt -= QCAP;
                 }
                 if (held && mw == __ballot(on)) __builtin_amdgcn_s_sleep(64); // (none of them may start yet: no hurry)
                 if (lane == 0) S.waitq = (uint32_t)wn | ((uint32_t)wh << 8) | ((uint32_t)wt << 16) | (held ? 0u : 1u << 24);
@@ -2225,6 +2573,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             atomicAdd(&cs[C_TESTS], (unsigned long long)c);
             atomicAdd(&cs[C_HITS], (unsigned long long)d);
             atomicMax(&cs[C_MAXSP], (unsigned long long)ms);
+            for (int p = 0; p < 5; p++) {
+                atomicAdd(&cs[C_DIAG + 2 * p], (unsigned long long)dg_b[p]);
+                atomicAdd(&cs[C_DIAG + 2 * p + 1], (unsigned long long)dg_l[p]);
+            }
         }
     }
 }
@@ -2495,6 +2847,8 @@ struct crt_scene {
     DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4;
     int depth4 = 1; // depth of the 4-wide tree
     bool ref16_ok = false; // refs of the 4-wide tree and of the leaf records fit 16 bits (k_mega3's 16-bit stack layout)
+    bool ref16_inner_ok = false; // refs of the 4-wide tree alone fit 16 bits (decoupled leaves: the stack holds inner nodes only)
+    bool dec_ok = false;         // leaf records fit the 24 bits of a leaf-queue entry
     uint32_t max_leaf = 0; // triangles in the largest leaf
     DevBuf<int32_t> tri_mat, leaf_count;
     DevBuf<uint4> lights;
@@ -2541,11 +2895,14 @@ struct crt_scene {
 };
 
 // 16-bit stack entries: the scene allows it (crt_scene::ref16_ok) and CRT_REF16=0 does not forbid it
-static bool use_ref16(const crt_scene* sc, int mode)
+static bool use_ref16(const crt_scene* sc, int mode, bool dec = false)
 {
-    if (mode == 1 || !sc->ref16_ok) return false;
-    const char* e = std::getenv("CRT_REF16"); // CRT_REF16=0: the 32-bit layout whatever the scene (tests, A/B)
-    return !(e && e[0] == '0');
+    if (mode == 1 || !(dec ? sc->ref16_inner_ok : sc->ref16_ok)) return false;
+    // CRT_REF16=0: the coupled form in its 32-bit layout whatever the scene; CRT_REF32=1: 32-bit stack entries in either form (tests, A/B)
+    const char* e = std::getenv("CRT_REF16");
+    const char* f = std::getenv("CRT_REF32");
+    if (f && f[0] == '1') return false;
+    return dec || !(e && e[0] == '0');
 }
 
 namespace {
@@ -2737,30 +3094,40 @@ uint32_t env_u32(const char* name, uint32_t dflt)
 // The instantiation of k_mega3 for a traversal mode (0 FAST, 1 REFERENCE, 2 EXACT), with or without counters, every sample traced
 // or not (FAST only), render or query form, 32- or 16-bit stack entries (never for REFERENCE)
 typedef void (*Mega3Kernel)(const MParams3);
-Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring = false)
+// The decoupled-leaves form (Pool4LdsT) of a launch: CRT_TRAVERSAL_EXACT on a scene whose leaf records fit a queue entry.  It is
+// the layout of the scenes whose leaf records no longer fit 16-bit stack entries while their four-wide nodes do (about 50 000 to
+// 160 000 triangles): its stack holds inner nodes only.  On the smaller scenes the coupled form is 1 - 3 % faster and
+// stays the default.  CRT_DEC=1 / 0 forces / forbids it (tests, A/B); CRT_REF16=0 ("the leaf records do not fit") selects it too.
+static bool use_dec(const crt_scene* sc, int mode)
 {
+    if (mode != 2 || !sc->dec_ok) return false;
+    const char* e = std::getenv("CRT_DEC");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    const char* r = std::getenv("CRT_REF16");
+    const bool fits16 = sc->ref16_ok && !(r && r[0] == '0');
+    return !fits16 && sc->ref16_inner_ok;
+}
+template <bool R16, bool DEC> Mega3Kernel mega3_exact_kernel(bool stats, bool all, bool query, bool ring)
+{
+    if (ring) return all ? (Mega3Kernel)k_mega3<2, false, true, false, R16, true, DEC> : (Mega3Kernel)k_mega3<2, false, false, false, R16, true, DEC>;
+    if (query) return (Mega3Kernel)k_mega3<2, false, false, true, R16, false, DEC>;
+    if (all) return stats ? (Mega3Kernel)k_mega3<2, true, true, false, R16, false, DEC> : (Mega3Kernel)k_mega3<2, false, true, false, R16, false, DEC>;
+    return stats ? (Mega3Kernel)k_mega3<2, true, false, false, R16, false, DEC> : (Mega3Kernel)k_mega3<2, false, false, false, R16, false, DEC>;
+}
+Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring = false, bool dec = false)
+{
+    if (mode == 2) {
+        if (dec) return r16 ? mega3_exact_kernel<true, true>(stats, all, query, ring) : mega3_exact_kernel<false, true>(stats, all, query, ring);
+        return r16 ? mega3_exact_kernel<true, false>(stats, all, query, ring) : mega3_exact_kernel<false, false>(stats, all, query, ring);
+    }
     if (ring) { // (a render without counters)
         if (mode == 1) return (Mega3Kernel)k_mega3<1, false, false, false, false, true>;
-        if (mode == 2) {
-            if (all) return r16 ? (Mega3Kernel)k_mega3<2, false, true, false, true, true> : (Mega3Kernel)k_mega3<2, false, true, false, false, true>;
-            return r16 ? (Mega3Kernel)k_mega3<2, false, false, false, true, true> : (Mega3Kernel)k_mega3<2, false, false, false, false, true>;
-        }
         if (all) return r16 ? (Mega3Kernel)k_mega3<0, false, true, false, true, true> : (Mega3Kernel)k_mega3<0, false, true, false, false, true>;
         return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, false, false, true>;
     }
     if (mode == 1) return query ? (Mega3Kernel)k_mega3<1, false, false, true> : stats ? (Mega3Kernel)k_mega3<1, true> : (Mega3Kernel)k_mega3<1, false>;
-    if (query) {
-        if (mode == 2) return r16 ? (Mega3Kernel)k_mega3<2, false, false, true, true> : (Mega3Kernel)k_mega3<2, false, false, true, false>;
-        return r16 ? (Mega3Kernel)k_mega3<0, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, true, false>;
-    }
-    if (mode == 2) {
-        if (all) {
-            if (stats) return r16 ? (Mega3Kernel)k_mega3<2, true, true, false, true> : (Mega3Kernel)k_mega3<2, true, true, false, false>;
-            return r16 ? (Mega3Kernel)k_mega3<2, false, true, false, true> : (Mega3Kernel)k_mega3<2, false, true, false, false>;
-        }
-        if (stats) return r16 ? (Mega3Kernel)k_mega3<2, true, false, false, true> : (Mega3Kernel)k_mega3<2, true, false, false, false>;
-        return r16 ? (Mega3Kernel)k_mega3<2, false, false, false, true> : (Mega3Kernel)k_mega3<2, false, false, false, false>;
-    }
+    if (query) return r16 ? (Mega3Kernel)k_mega3<0, false, false, true, true> : (Mega3Kernel)k_mega3<0, false, false, true, false>;
     if (all) {
         if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, true, false, true> : (Mega3Kernel)k_mega3<0, true, true, false, false>;
         return r16 ? (Mega3Kernel)k_mega3<0, false, true, false, true> : (Mega3Kernel)k_mega3<0, false, true, false, false>;
@@ -2768,6 +3135,9 @@ Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, b
     if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, false, false, true> : (Mega3Kernel)k_mega3<0, true, false, false, false>;
     return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true> : (Mega3Kernel)k_mega3<0, false, false, false, false>;
 }
+// rays per wave / stack levels in LDS of a launch's kernel
+static uint32_t mega3_pool_p(bool dec, bool ring) { return dec ? (ring ? (uint32_t)Pool4LdsT<true, true>::P : (uint32_t)Pool4LdsT<true, false>::P) : (uint32_t)POOL3_P; }
+static int mega3_lds_levels(bool dec, bool r16) { return dec ? (r16 ? Pool4LdsT<true, false>::LV : Pool4LdsT<false, false>::LV) : POOL_LV; }
 // Diagnostic hook (tools/bbprof): CRT_BBPROF_CO names a code object holding the default instantiation of k_mega3 with a counting
 // prologue in every basic block (tools/bbprof/instrument.py applied to the compiler's assembly of THIS file); the launch then goes
 // to that copy, the address of its counter buffer travels in MParams3::dbg_loads / dbg_valu, and the summed counters
@@ -2776,7 +3146,11 @@ Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, b
 bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t st)
 {
     static const char* co = std::getenv("CRT_BBPROF_CO");
-    if (!co || !*co || kern != (Mega3Kernel)k_mega3<2, false, false, false, true>) return false;
+    // (the default instantiations: 16-bit stack entries, CRT_TRAVERSAL_EXACT, with the leaves decoupled or not)
+    const char* sym = kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, true>    ? "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1EEEvNS_8MParams3E"
+                      : kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, false> ? "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
+                                                                                                  : nullptr;
+    if (!co || !*co || !sym) return false;
     enum { N_CNT = 4096, STRIDE = 128 };
     static hipModule_t mod = nullptr;
     static hipFunction_t fn = nullptr;
@@ -2785,7 +3159,7 @@ bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t s
     static std::vector<unsigned long long> sum(N_CNT, 0ull);
     if (!fn) {
         HIP_CHECK(hipModuleLoad(&mod, co));
-        HIP_CHECK(hipModuleGetFunction(&fn, mod, "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0EEEvNS_8MParams3E"));
+        if (hipModuleGetFunction(&fn, mod, sym) != hipSuccess) { fn = nullptr; return false; } // (the code object holds the other form)
         HIP_CHECK(hipMalloc((void**)&buf, 2 * (size_t)N_CNT * STRIDE));
         // the prologues add block offsets to the low address word without a carry: the counters must not straddle a 4 GiB boundary
         cnt = buf;
@@ -2960,12 +3334,12 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             // ---------- fused persistent megakernel: one launch per chunk ----------
             const bool reference = prm->traversal == CRT_TRAVERSAL_REFERENCE;
             const bool exact = prm->traversal == CRT_TRAVERSAL_EXACT;
-            const int lds_cap = POOL_LV;
             const int mode_id = (reference ? 2 : exact ? 4 : 0) + (want_stats ? 1 : 0);
             const int mode3 = reference ? 1 : exact ? 2 : 0;
-            const bool r16 = use_ref16(sc, mode3);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16, ring.samples != 0);
-            const uint32_t pool_p = (uint32_t)POOL3_P;
+            const bool dec = use_dec(sc, mode3);
+            const bool r16 = use_ref16(sc, mode3, dec);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16, ring.samples != 0, dec);
+            const uint32_t pool_p = mega3_pool_p(dec, ring.samples != 0);
             MParams M;
             std::memset(&M, 0, sizeof(M));
             int per_cu = 1;
@@ -2986,7 +3360,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             sc->p_rec_a.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
             sc->p_rec_b.ensure((size_t)lanes * CRT_BOUNCE_STACK_SIZE);
             // (16-bit layout: a ray on the reference-arithmetic path keeps its whole stack in the global area)
-            const int spill_levels = r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - POOL_LV);
+            const int lds_cap = mega3_lds_levels(dec, r16);
+            const int spill_levels = r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - lds_cap);
             sc->spill[0].ensure((size_t)spill_levels * lanes);
             Pool pool;
             std::memset(&pool, 0, sizeof(pool));
@@ -3534,17 +3909,31 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                     o[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]);
                 }
                 o[6] = make_float4(as_float(refs[0]), as_float(refs[1]), as_float(refs[2]), as_float(refs[3]));
-                o[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                // the refs as the decoupled-leaves step wants them: a leaf as 0x80000000 | record << 8, ready to take the ray id
+                // (records beyond 2^23 - 1 do not fit: crt_scene::dec_ok)
+                auto dref = [](int32_t r) -> int32_t { return r >= 0 ? r : (int32_t)(0x80000000u | (((uint32_t)~r & 0x7fffffu) << 8)); };
+                o[7] = make_float4(as_float(dref(refs[0])), as_float(dref(refs[1])), as_float(dref(refs[2])), as_float(dref(refs[3])));
             }
         }
         if (nodes4.empty()) nodes4.resize(8);
+        const size_t n_nodes4 = nodes4.size() / 8;
+        {
+            // the empty node behind the tree (DevScene::empty4_off): four inverted boxes, refs that are never followed
+            const float pinf_ = std::numeric_limits<float>::infinity();
+            for (int a = 0; a < 3; a++) { nodes4.push_back(make_float4(pinf_, pinf_, pinf_, pinf_)); nodes4.push_back(make_float4(-pinf_, -pinf_, -pinf_, -pinf_)); }
+            const float er = as_float(~0x7ffffff0);
+            nodes4.push_back(make_float4(er, er, er, er)); nodes4.push_back(make_float4(er, er, er, er));
+            sc->dev.empty4_off = (uint32_t)(n_nodes4 * 128);
+        }
         sc->nodes4.upload(nodes4);
         sc->dev.nodes4 = sc->nodes4.p;
         sc->dev.root4 = root4;
         sc->dev.coord_max = coord_max;
         sc->depth4 = depth4;
-        sc->accel.n_nodes4 = (uint32_t)(nodes4.size() / 8); sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
-        sc->ref16_ok = nodes4.size() / 8 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
+        sc->accel.n_nodes4 = (uint32_t)n_nodes4; sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
+        sc->ref16_ok = n_nodes4 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
+        sc->ref16_inner_ok = n_nodes4 <= 32768;
+        sc->dec_ok = leaf_geo.size() / 5 <= (size_t)LEAF_REC_MAX + 1;
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
@@ -3776,14 +4165,15 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             int per_cu = 1;
             const bool exact = traversal == CRT_TRAVERSAL_EXACT;
             const int mode3 = reference ? 1 : exact ? 2 : 0;
-            const bool r16 = use_ref16(sc, mode3);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, false, false, true, r16);
+            const bool dec = use_dec(sc, mode3);
+            const bool r16 = use_ref16(sc, mode3, dec);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, false, false, true, r16, false, dec);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern3, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-            const uint32_t pool_p = (uint32_t)POOL3_P;
+            const uint32_t pool_p = mega3_pool_p(dec, false);
             const uint32_t blocks = std::min<uint32_t>((n + pool_p - 1) / pool_p, (uint32_t)(sc->n_cus * per_cu));
             const uint32_t lanes = blocks * pool_p;
             sc->p_la.ensure(lanes); sc->p_id.ensure(lanes); sc->L.ensure(n);
-            sc->spill[0].ensure((size_t)(r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - POOL_LV)) * lanes);
+            sc->spill[0].ensure((size_t)(r16 ? std::max(1, sc->stack_cap) : std::max(1, sc->stack_cap - mega3_lds_levels(dec, r16))) * lanes);
             MParams3 M3;
             std::memset(&M3, 0, sizeof(M3));
             LParams& P = M3.M.P;
@@ -3794,7 +4184,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             P.item_next = sc->item_next.p; P.L = sc->L.p; P.counters = sc->counters.p;
             P.q_o = sc->p_ro.p; P.q_d = sc->p_rd.p;
             P.nslots = 1; P.nslots_div = make_fastdiv(1); P.tiles_x = 1; P.tiles_x_div = make_fastdiv(1); P.lsn_div = make_fastdiv(1);
-            M3.M.sc = sc->dev; M3.M.counters = sc->counters.p; M3.M.spill_stride = lanes; M3.M.stack_cap = POOL_LV;
+            M3.M.sc = sc->dev; M3.M.counters = sc->counters.p; M3.M.spill_stride = lanes; M3.M.stack_cap = mega3_lds_levels(dec, r16);
             M3.spill = (int*)sc->spill[0].p;
             M3.force_exact = force_exact ? 1u : 0u;
             HIP_CHECK(hipMemsetAsync(sc->item_next.p, 0, (size_t)ITEM_SHARDS * ITEM_STRIDE * sizeof(unsigned int), nullptr));

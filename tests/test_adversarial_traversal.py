@@ -452,11 +452,22 @@ def test_raw_directions_with_infinite_components():
         r.free()
 
 
+LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_kernels.hip: use_dec, use_ref16)
+    "coupled-16": {"CRT_DEC": "0"},
+    "coupled-32": {"CRT_DEC": "0", "CRT_REF16": "0"},
+    "decoupled-16": {"CRT_DEC": "1"},
+    "decoupled-32": {"CRT_DEC": "1", "CRT_REF32": "1"},
+    "auto, leaf records beyond 16 bits": {"CRT_REF16": "0"},  # what a scene of 50 000 - 160 000 triangles gets: decoupled-16
+}
+
+
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
-def test_both_stack_layouts(name, monkeypatch):
-    """k_mega3 keeps six 16-bit traversal-stack levels in LDS where the scene's refs fit (both benchmark scenes) and three 32-bit
-    levels otherwise (CRT_REF16=0 forces that layout); in the 16-bit layout a ray on the reference-arithmetic path keeps its whole
-    stack in the global spill area (CRT_FLAG_FORCE_EXACT puts every ray there).  Same frames, same ray counts, same closest hits."""
+def test_all_stack_layouts(name, monkeypatch):
+    """k_mega3's pool has two forms.  Coupled: a ray walks inner nodes and leaves alike, eight 16-bit traversal-stack levels in LDS
+    where node AND leaf refs fit 16 bits (both benchmark scenes), four 32-bit levels otherwise.  Decoupled leaves (CRT_TRAVERSAL_EXACT):
+    the stack holds inner nodes only -- six 16-bit levels while the four-wide nodes number at most 32 768, else three of 32 bits --
+    and the leaf tests are entries of a queue.  In a 16-bit layout a ray on the reference-arithmetic path keeps its whole stack in the
+    global spill area (CRT_FLAG_FORCE_EXACT puts every ray there).  Same frames, same ray counts, same closest hits in every form."""
     t = util.task(name)
     eye, iv, fov = util.camera(name)
     osc = util.oracle_scene(name)
@@ -465,17 +476,21 @@ def test_both_stack_layouts(name, monkeypatch):
         orgb, omean, _, st = osc.render(eye, iv, fov, 96, 72, 3, t.P_RR, t.light_sample_n)
         o, d = util.random_rays(name, 4096, seed=17)
         otri, ot, _ = osc.intersect(o, d)
-        for ref16 in ("1", "0"):
-            monkeypatch.setenv("CRT_REF16", ref16)
+        for layout, env in LAYOUTS.items():
+            for k in ("CRT_DEC", "CRT_REF16", "CRT_REF32"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
             for mode, flags in ((crt.TRAVERSAL_FAST, 0), (crt.TRAVERSAL_EXACT, 0), (crt.TRAVERSAL_FAST, crt.FLAG_FORCE_EXACT),
                                 (crt.TRAVERSAL_EXACT, crt.FLAG_FORCE_EXACT), (crt.TRAVERSAL_REFERENCE, 0)):
                 r.traversal, r.extra_flags = mode, flags
                 rgb = r.run_view(eye, iv, fov, width=96, height=72)
-                assert np.array_equal(rgb, orgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (ref16, mode, flags)
+                assert np.array_equal(rgb, orgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (layout, mode, flags)
                 assert r.stats["rays"] == st["rays"]
             r.extra_flags = 0
-            for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT, crt.TRAVERSAL_REFERENCE):
+            for mode in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT, crt.TRAVERSAL_FAST | crt.INTERSECT_FORCE_EXACT,
+                         crt.TRAVERSAL_EXACT | crt.INTERSECT_FORCE_EXACT, crt.TRAVERSAL_REFERENCE):
                 tri, tt = r.intersect(o, d, traversal=mode)
-                assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot)), (ref16, mode)
+                assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot)), (layout, mode)
     finally:
         r.free()

@@ -179,7 +179,10 @@ def test_small_full_frame_matches_oracle_with_counters(renders, name):
             exact_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
         else:
             fast_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
-    assert exact_visits[0] >= fast_visits[0] and exact_visits[1] >= fast_visits[1]  # pruning only ever removes visits
+    # pruning only ever removes visits -- between two walks in the same order: with the leaves decoupled (CRT_DEC=1) an any-hit ray
+    # of EXACT meets its leaves in another order than FAST's and may stop earlier
+    if os.environ.get("CRT_DEC") != "1":
+        assert exact_visits[0] >= fast_visits[0] and exact_visits[1] >= fast_visits[1]
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])

@@ -4,7 +4,7 @@
 set -e -o pipefail
 here=$(cd "$(dirname "$0")" && pwd); root=$(cd "$here/../.." && pwd)
 out=${1:-$root/tools/bbprof/out}; mkdir -p "$out"
-sym=${CRT_BBPROF_SYM:-_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0EEEvNS_8MParams3E}
+sym=${CRT_BBPROF_SYM:-_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E}  # the default render kernel (coupled form); ...ELb1ELb0ELb1E... = decoupled leaves (run with CRT_DEC=1)
 flags=$(python3 -c "import sys; sys.path.insert(0, '$root'); from cudaraytracing_amd import build as b; print(' '.join(b.COMMON + b.DEVICE))")
 llvm=/opt/rocm/lib/llvm/bin
 /opt/rocm/bin/hipcc $flags -gline-tables-only -S --cuda-device-only -o "$out/crt_kernels.s" "$root/cudaraytracing_amd/csrc/crt_kernels.hip" 2> /dev/null

@@ -25,7 +25,8 @@ def phase_ranges():
     """Line ranges of the phase arms of k_mega3's main loop, found by their markers in the source."""
     lines = open(os.path.join(SRC, "crt_kernels.hip")).read().split("\n")
     k0 = next(i for i, l in enumerate(lines) if "void k_mega3(const MParams3 M3)" in l) + 1
-    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"auto inner_arm = "), ("leaf", r"auto leaf_arm = "), ("sched2", r"^\s*if \(act == PH3_INNER\) \{"),
+    marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"auto inner_arm = "), ("leaf", r"auto leaf_arm = "), ("inner", r"auto inner_arm_dec = "), ("leaf", r"auto leaf_arm_dec = "),
+             ("sched2", r"^\s*const bool plain = MODE == 1 \|\| n_exact == 0;"),
              ("LA", r"if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"^\s*\} else \{\s*$"), ("end", r"^#undef PUSH3")]
     at, cur = [], k0
     for name, pat in marks:
@@ -42,7 +43,8 @@ def phase_ranges():
     calls = []
     for i, l in enumerate(lines):
         for name, pat in (("inner", "inner_arm(std::false_type{})"), ("inner_ex", "inner_arm(std::true_type{})"), ("leaf", "leaf_arm(std::false_type{})"),
-                          ("leaf_ex", "leaf_arm(std::true_type{})")):
+                          ("leaf_ex", "leaf_arm(std::true_type{})"), ("inner", "inner_arm_dec(std::false_type{})"), ("inner_ex", "inner_arm_dec(std::true_type{})"),
+                          ("leaf", "leaf_arm_dec()")):
             if pat in l:
                 calls.append((name, i + 1, i + 1))
     return calls + rng
