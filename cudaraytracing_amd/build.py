@@ -20,8 +20,8 @@ HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"] + os.environ.get("CRT_EXTRA_CXXFLAGS", "").split()
 DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt"]
 
-LIB_SOURCES = ["crt_kernels.hip", "crt_multi.hip", "crt_bvh_build.hip", "crt_accel_build.hip", "crt_host.cpp"]
-LIB_DEPS = LIB_SOURCES + ["crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", "crt_png.h", "crt_jpeg.h", "crt_formats.h", "crt_image.h", "crt_bvh_build.h",
+LIB_SOURCES = ["crt_mega3.hip", "crt_wavefront.hip", "crt_frame.hip", "crt_render.hip", "crt_multi.hip", "crt_bvh_build.hip", "crt_accel_build.hip", "crt_host.cpp"]
+LIB_DEPS = LIB_SOURCES + ["crt_path.h", "crt_mega3.h", "crt_internal.h", "crt_device.h", "crt_trace.h", "crt_accel.h", "crt_detmath.h", "crt_host.hpp", "crt_png.h", "crt_jpeg.h", "crt_formats.h", "crt_image.h", "crt_bvh_build.h",
                           os.path.join("..", "..", "include", "crt.h")]
 FLAGS_FILE = os.path.join(LIBDIR, "libcrt.flags")  # the flag string libcrt.so was built with (a variant build is stale for a default run)
 
@@ -39,7 +39,7 @@ def built_flags():
         return ""
 
 
-KERNEL_DEPS = ["crt_kernels.hip", "crt_device.h", "crt_trace.h", "crt_accel.h", "crt_accel_build.hip", "crt_detmath.h"]  # what the render kernels are made of
+KERNEL_DEPS = ["crt_mega3.hip", "crt_mega3.h", "crt_path.h", "crt_render.hip", "crt_device.h", "crt_trace.h", "crt_accel.h", "crt_accel_build.hip", "crt_detmath.h"]  # what the render kernel is made of, and the host code that lays out what it walks
 
 
 def _code_only(text):

@@ -108,7 +108,7 @@ def test_soup_with_duplicates_matches_the_oracle(tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
 def test_collapse_by_dynamic_programming_against_the_greedy_one(name, monkeypatch):
-    """The 4-wide collapse minimises the summed area of the wide nodes (dynamic programming, csrc/crt_kernels.hip); the round-1 rule
+    """The 4-wide collapse minimises the summed area of the wide nodes (dynamic programming, csrc/crt_render.hip); the round-1 rule
     (CRT_COLLAPSE=greedy: open the largest child until there are four) stays selectable.  Same frame either way (any tree over the
     reference's leaves gives the same hits); the optimal collapse has no more nodes and no more inner steps on the frame."""
     t = util.task(name)

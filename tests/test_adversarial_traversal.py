@@ -216,7 +216,7 @@ def test_grazing_rays_on_the_shipped_scenes():
 
 
 # ----------------------------------------------------------------------------------------------
-# The fallbacks of the pipeline choice (csrc/crt_kernels.hip: choose_pipeline): scenes beyond k_mega3's 16-bit leaf offsets,
+# The fallbacks of the pipeline choice (csrc/crt_render.hip: choose_pipeline): scenes beyond k_mega3's 16-bit leaf offsets,
 # 32-bit byte offsets or 8-bit stack depth render with the wavefront pipeline.  The CRT_TEST_* hooks lower each limit so
 # that an ordinary scene trips it; the frame must not change (and the many trace launches show which pipeline ran).
 # ----------------------------------------------------------------------------------------------
@@ -452,7 +452,7 @@ def test_raw_directions_with_infinite_components():
         r.free()
 
 
-LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_kernels.hip: use_dec, use_ref16)
+LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_render.hip: use_dec, use_ref16)
     "coupled-16": {"CRT_DEC": "0"},
     "coupled-32": {"CRT_DEC": "0", "CRT_REF16": "0"},
     "decoupled-16": {"CRT_DEC": "1"},

@@ -1,4 +1,4 @@
-"""GPU tests of the commit ring (CRT_FLAG_BOUNDED_RADIANCE, csrc/crt_kernels.hip: ring_publish / ring_commit): the frame's sum
+"""GPU tests of the commit ring (CRT_FLAG_BOUNDED_RADIANCE, csrc/crt_path.h: ring_publish / ring_commit): the frame's sum
 c += L_k / spp (reference: Render.cuh:348) made in sample order INSIDE the launch with radiance storage for a window of samples.
 The ring changes where and when the additions happen, never their order: every frame here must be, bit for bit (f32 sums and RGB8),
 the frame of the default path, which keeps one radiance per path and sums after the launch."""

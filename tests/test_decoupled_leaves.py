@@ -1,4 +1,4 @@
-"""The decoupled-leaves form of k_mega3 (csrc/crt_kernels.hip: Pool4LdsT, inner_arm_dec / leaf_arm_dec), forced with CRT_DEC=1 on
+"""The decoupled-leaves form of k_mega3 (csrc/crt_mega3.h: Pool4LdsT; crt_mega3.hip:, inner_arm_dec / leaf_arm_dec), forced with CRT_DEC=1 on
 the cases where its differences from the coupled form could show: the tie rule across leaves now rests on one LDS atomic minimum
 over (distance, ~triangle) instead of the order of the visits (DeviceBVH.cuh:34-41,144; csrc/crt_trace.h), leaves of many records
 are resolved inside one queue entry, rays on the reference-arithmetic path hand their leaves over one by one, a scene that is one

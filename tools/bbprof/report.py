@@ -23,7 +23,7 @@ SRC = os.path.join(ROOT, "cudaraytracing_amd", "csrc")
 
 def phase_ranges():
     """Line ranges of the phase arms of k_mega3's main loop, found by their markers in the source."""
-    lines = open(os.path.join(SRC, "crt_kernels.hip")).read().split("\n")
+    lines = open(os.path.join(SRC, "crt_mega3.hip")).read().split("\n")
     k0 = next(i for i, l in enumerate(lines) if "void k_mega3(const MParams3 M3)" in l) + 1
     marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"auto inner_arm = "), ("leaf", r"auto leaf_arm = "), ("inner", r"auto inner_arm_dec = "), ("leaf", r"auto leaf_arm_dec = "),
              ("sched2", r"^\s*const bool plain = MODE == 1 \|\| n_exact == 0;"),
@@ -53,7 +53,7 @@ def phase_ranges():
 def function_map():
     """file -> sorted list of (first line, name) of the function definitions in the kernel sources."""
     out = {}
-    for fn in ("crt_kernels.hip", "crt_device.h", "crt_detmath.h", "crt_trace.h"):
+    for fn in ("crt_mega3.hip", "crt_mega3.h", "crt_path.h", "crt_device.h", "crt_detmath.h", "crt_trace.h"):
         defs = []
         for i, l in enumerate(open(os.path.join(SRC, fn)).read().split("\n")):
             if not re.match(r"^(__device__|__global__|static|inline|__host__|CRT_HD)\b", l) or l.rstrip().endswith(";"):

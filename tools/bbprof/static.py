@@ -2,7 +2,7 @@
 """Static look at the compiler's code for one kernel (no GPU): per phase of k_mega3's main loop (attributed through the inlined-at
 chains, as report.py does) the vector instructions by kind -- arithmetic against register traffic (v_mov / v_readlane /
 v_writelane / v_readfirstlane: copies at joins, SGPR spills, uniform values parked in vector registers) -- and the register
-numbers.  usage: static.py <crt_kernels.s> [kernel symbol]"""
+numbers.  usage: static.py <crt_mega3.s> [kernel symbol]"""
 import collections
 import os
 import re
@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import report  # noqa: E402
 
-SYM = "_ZN12_GLOBAL__N_17k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
+SYM = "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
 
 
 def main():
