@@ -22,15 +22,16 @@ rays; the count is deterministic given (scene, config, seed) and comes from the 
 roofline -- dominant kernel k_mega3 (persistent path-tracing megakernel, one launch per frame).  The kernel's time is
 measured live (HIP events on the launching stream); the counts it is set against come from rocprofv3 PMC passes of
 the same workload, kept in profiles/pmc_latest.json and STAMPED with a hash of the kernel sources and build flags:
-when the hash differs from the library that is running, the counter-based fields are null (never a stale number).
-Three candidate bounds are priced, each with a fraction <= 1 by construction, and the largest one is reported as
-`roofline.frac` / `roofline.bound`:
-    hbm        memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected as MI355X_MICROARCH.md
-               prescribes) / t against 8 TB/s;
-    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / (cycles per wave64 VALU instruction of THIS kernel's mix: the exact
-               dynamic opcode census of tools/bbprof -- executions of every basic block of the production ISA -- priced with the
-               per-opcode issue costs of tools/valu_issue_gen.py, profiles/bbprof_latest.json, hash-stamped like the PMC file;
-               `frac_at_guide_peak` prices the same count at the guide's 2 cycles per instruction);
+when the hash differs from the library that is running (or CRT_LIB_PATH loads another library), the counter-based
+fields are null (never a stale number).  Three candidate bounds are priced against DATASHEET peaks only
+(MI355X_MICROARCH.md), every fraction <= 1, and the largest is `roofline.frac` / `roofline.bound`:
+    hbm        memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected as the guide prescribes) / t
+               against 8 TB/s; `frac_without_x2` beside it (the x2 is exact for wide streaming reads only);
+    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / 2 (the guide's 2 cycles per wave64 instruction).  Beside it, NOT
+               used to pick the bound: `frac_at_mix_cost` (the same count priced with the cycles per instruction of THIS
+               kernel's opcode mix: the exact census of tools/bbprof x the per-opcode costs of tools/valu_issue_gen.py),
+               `valu_busy_hw` (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles: how busy the vector pipes were, by the hardware's own
+               counter) and `arith_share` (share of the vector instructions that are box / triangle arithmetic);
     l2         TCC requests x 128 B / t against the L2 peak.
 The SURVEY 8(d) contract figure -- algorithmic bytes of the REFERENCE traversal's visit set, B_ray = 64 x inner
 visits + 8 x leaf visits + 36 x triangle tests + 16 x hits, counted by the exhaustive kernel on a spp=8 slice --
@@ -56,6 +57,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# BASELINE.json configs: scene, width, height, spp (C1 is C2's scene at spp 2 on the CPU: the cpu_baseline leg)
+WORKLOADS = {"c2": ("cornell-box", 800, 600, 512), "c3": ("veach-mis", 800, 600, 1024),
+             "c4": ("cornell-box", 3840, 2160, 256), "c5": ("veach-mis", 1920, 1080, 4096)}
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E (MI355X_MICROARCH.md)
 L2_PEAK_GBPS = 34500.0       # 8 XCDs x 16 channels x 128 B/clk at 2.1 GHz
 N_SIMDS = 1024               # 256 CUs x 4
@@ -70,10 +74,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)  # (the first two frames after start-up run 1 % slower: clocks and caches settle)
-    ap.add_argument("--scene", default="cornell-box")
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--height", type=int, default=600)
-    ap.add_argument("--spp", type=int, default=512)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="a BASELINE.json configuration: c2 (default) cornell-box 800x600 spp 512, c3 veach-mis 800x600 spp 1024, "
+                         "c4 cornell-box 3840x2160 spp 256, c5 veach-mis 1920x1080 spp 4096 (c4 / c5 are the 8-GPU configurations; "
+                         "they run on any N).  --scene / --width / --height / --spp override single fields")
+    ap.add_argument("--scene", default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--traversal", default="exact", choices=["exact", "fast", "reference"],
                     help="exact (default): provably the reference's frame; fast: + distance pruning (measured rate of lost rays, include/crt.h)")
@@ -89,7 +97,16 @@ def parse_args():
                          "share of C2 at 1 / 2 / 4 / 8 ranks (tools/pipeline_probe.py), but k_accumulate of frame i then waits for "
                          "kernel i+1 (no free VGPRs) and a frame's latency doubles -- an option, not the reported number")
     ap.add_argument("--save-png", default=None)
-    return ap.parse_args()
+    ap.add_argument("--no-large-scene", action="store_true", help="skip the large-mesh sub-record (a 126 000-triangle variant of the scene, and the stand-in under the large-mesh layout)")
+    a = ap.parse_args()
+    w = WORKLOADS[a.workload or "c2"]
+    explicit = any(v is not None for v in (a.scene, a.width, a.height, a.spp))
+    a.scene = a.scene or w[0]
+    a.width = a.width or w[1]
+    a.height = a.height or w[2]
+    a.spp = a.spp or w[3]
+    a.workload_id = next((k for k, v in WORKLOADS.items() if v == (a.scene, a.width, a.height, a.spp)), None) if (explicit or a.workload is None) else a.workload
+    return a
 
 
 def spawn_ranks(args):
@@ -137,6 +154,8 @@ def spawn_ranks(args):
 def load_pmc(workload_key):
     """Counters of `workload_key` from profiles/pmc_latest.json if they were collected on the code that is running."""
     from cudaraytracing_amd import build as B
+    if os.environ.get("CRT_LIB_PATH"):
+        return None, "CRT_LIB_PATH loads a library of unknown sources: no hash-stamped counters are attached"
     try:
         d = json.load(open(PMC_FILE))
     except Exception:
@@ -153,6 +172,8 @@ def load_pmc(workload_key):
 def load_census(workload_key):
     """The instruction census of `workload_key` (tools/bbprof/census.py) if it was taken on the code that is running."""
     from cudaraytracing_amd import build as B
+    if os.environ.get("CRT_LIB_PATH"):
+        return None
     try:
         d = json.load(open(CENSUS_FILE))
     except Exception:
@@ -163,39 +184,49 @@ def load_census(workload_key):
 
 
 def bounds_from_pmc(pmc, k_s, census=None):
-    """The three candidate bounds for one launch of duration k_s seconds; every fraction is <= 1 by construction.
-    census (tools/bbprof): exact dynamic opcode counts priced with measured per-opcode issue costs -- the cycles per vector
-    instruction of THIS kernel's mix; without it the round-2 estimate from the coarse SQ_INSTS_VALU_* classes is used."""
+    """The candidate bounds for one launch of duration k_s seconds, each against a datasheet peak (MI355X_MICROARCH.md) and clamped to
+    1.  census (tools/bbprof): exact dynamic opcode counts priced with measured per-opcode issue costs -- side fields only."""
     out = {}
-    cyc = float(pmc.get("valu_cycles_per_instr", 3.35))
-    if census:
-        cyc = float(census["cycles_per_valu"])
+
+    def frac(x):
+        return round(min(1.0, x), 4)
     if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
         traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
+        plain = pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
         out["hbm"] = {"achieved": round(traffic / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                      "frac": round(traffic / k_s / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": traffic}
+                      "frac": frac(traffic / k_s / 1e9 / HBM_PEAK_GBPS), "bytes_per_launch": traffic,
+                      "frac_without_x2": frac(plain / k_s / 1e9 / HBM_PEAK_GBPS), "bytes_per_launch_without_x2": plain,
+                      "note": "2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; the x2 is exact for wide streaming reads, "
+                              "this kernel's reads are 16-byte gathers: the truth lies between the two fractions"}
     if pmc.get("SQ_INSTS_VALU") is not None:
-        peak = N_SIMDS * CLOCK_GHZ / cyc
+        peak = N_SIMDS * CLOCK_GHZ / GUIDE_VALU_CYCLES
         ach = pmc["SQ_INSTS_VALU"] / k_s / 1e9
-        out["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
-                             "cycles_per_instr": cyc, "lane_utilization": pmc.get("valu_lane_utilization")}
-        rng = census["cycles_per_valu_range"] if census else pmc.get("valu_cycles_per_instr_range")
-        if rng:  # the unpriced instructions at the cheapest / the dearest measured issue cost
-            out["valu_issue"]["frac_range"] = [round(ach * rng[0] / (N_SIMDS * CLOCK_GHZ), 4), round(ach * rng[1] / (N_SIMDS * CLOCK_GHZ), 4)]
-        out["valu_issue"]["frac_at_guide_peak"] = round(ach * GUIDE_VALU_CYCLES / (N_SIMDS * CLOCK_GHZ), 4)  # 2 cycles per instruction
-        out["valu_issue"]["cycles_per_instr_source"] = ("census: exact dynamic opcode counts (tools/bbprof) x measured per-opcode issue costs "
-                                                        "(tools/valu_issue_gen.py), %.2f %% of the instructions unpriced" % (100.0 * census["unpriced_share"])
-                                                        if census else "round-2 estimate from the SQ_INSTS_VALU_* classes")
+        v = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": frac(ach / peak),
+             "peak_note": "SIMDs x clock / 2 cycles per wave64 instruction (the guide's figure)", "lane_utilization": pmc.get("valu_lane_utilization")}
+        if pmc.get("SQ_ACTIVE_INST_VALU") is not None:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's vector pipe executed: x 4 / (SIMDs x clock x t)
+            v["valu_busy_hw"] = frac(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * CLOCK_GHZ * 1e9 * k_s))
         if census:
-            out["valu_issue"]["census"] = {"valu_instructions_per_launch": census["valu_instructions_per_launch"], "lane_utilisation": round(census["lane_utilisation"], 4),
-                                           "tiers": {k: round(v, 4) for k, v in census["tiers"].items()},
-                                           "pmc_over_census_instructions": round(pmc["SQ_INSTS_VALU"] / census["valu_instructions_per_launch"], 4)}
+            cyc = float(census["cycles_per_valu"])
+            v["frac_at_mix_cost"] = frac(ach * cyc / (N_SIMDS * CLOCK_GHZ))
+            v["mix_cycles_per_instr"] = round(cyc, 4)
+            rng = census.get("cycles_per_valu_range")
+            if rng:
+                v["frac_at_mix_cost_range"] = [frac(ach * rng[0] / (N_SIMDS * CLOCK_GHZ)), frac(ach * rng[1] / (N_SIMDS * CLOCK_GHZ))]
+            v["arith_share"] = round(census["arith_share"], 4) if census.get("arith_share") is not None else None
+            v["traversal_bookkeeping_share"] = round(census["traversal_bookkeeping_share"], 4) if census.get("traversal_bookkeeping_share") is not None else None
+            v["path_logic_share"] = round(census["path_logic_share"], 4) if census.get("path_logic_share") is not None else None
+            v["census"] = {"valu_instructions_per_launch": census["valu_instructions_per_launch"], "lane_utilisation": round(census["lane_utilisation"], 4),
+                           "tiers": {k: round(x, 4) for k, x in census["tiers"].items()}, "unpriced_share": round(census["unpriced_share"], 5),
+                           "pmc_over_census_instructions": round(pmc["SQ_INSTS_VALU"] / census["valu_instructions_per_launch"], 4),
+                           "source": "tools/bbprof (exact dynamic opcode counts of the production ISA) x tools/valu_issue_gen.py (measured per-opcode issue costs)"}
+        out["valu_issue"] = v
     if pmc.get("TCC_REQ_sum") is not None or (pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None):
         req = pmc.get("TCC_REQ_sum")
         if req is None:
             req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
         ach = req * 128.0 / k_s / 1e9
-        out["l2"] = {"achieved": round(ach, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / L2_PEAK_GBPS, 4)}
+        out["l2"] = {"achieved": round(ach, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": frac(ach / L2_PEAK_GBPS)}
     return out
 
 
@@ -276,7 +307,11 @@ def main_rank(args):
         ai = render.accel_info()
         setup.update({"bvh_device": {"total_ms": round(bi["total_ms"], 2), "level_loop_ms": round(bi["device_ms"], 2), "host_sorts": bi["host_sorts"],
                                      "host_triangles": bi["host_triangles"], "byte_identical_to_host_build": bool(same)},
-                      "sah_tree": {"on_device": bool(ai["sah_on_device"]), "ms": round(ai["sah_ms"], 2), "leaves": ai["n_leaves"], "nodes4": ai["n_nodes4"]}})
+                      "sah_tree": {"on_device": bool(ai["sah_on_device"]), "ms": round(ai["sah_ms"], 2), "device_ms": round(ai["sah_device_ms"], 2),
+                                   "leaves": ai["n_leaves"], "nodes4": ai["n_nodes4"]},
+                      # the HIP runtime's one-off start in this process (context, code objects), paid by whatever touches the device first:
+                      # timed by itself (crt_accel_info.runtime_init_ms); rounds 1-3 booked it on the SAH build ("147 ms")
+                      "runtime_init_ms": round(ai["runtime_init_ms"], 2)})
         s2.free()
 
     def step():
@@ -288,6 +323,7 @@ def main_rank(args):
         return render_sharded(render, eye, inv_view, fov, args.width, args.height, rank, world, device)
 
     kernel_ms, logic_ms, kernel_launches = [], [], []
+    kernel_ms_missing = 0   # frames without a megakernel launch to time (the fallback pipeline)
     rays_local = 0
     untraced_local = 0
     img = None
@@ -318,6 +354,7 @@ def main_rank(args):
         assert len(pipe.done) == args.steps
         img = pipe.done[-1]
         kernel_ms = list(pipe.kernel_ms)
+        kernel_ms_missing = pipe.kernel_ms_missing
     else:
         for _ in range(args.warmup):
             step()
@@ -363,7 +400,8 @@ def main_rank(args):
     single = n_gpus == 1
 
     if rank == 0:
-        c2 = args.scene == "cornell-box" and (args.width, args.height, args.spp) == (800, 600, 512)
+        wl = args.workload_id          # "c2" .. "c5" when the run is exactly that BASELINE configuration, else None
+        c2 = wl == "c2"
         # ---- contract figure: bytes per ray from the counting kernels on a spp=8 slice of the same frame; the same two renders
         #      give the FAST == REFERENCE cross-check (every pixel of the slice, float bits) ----
         def visit_bytes(st, node_bytes=64.0):
@@ -407,9 +445,9 @@ def main_rank(args):
                                      "does not perform that work (4-wide SAH tree over the same leaves, any-hit visibility rays, untraced zero-contribution samples), so this is not a bound",
                     "reference_visits_per_ray": ref_visits, "exact_visits_per_ray": visits["exact"], "fast_visits_per_ray": visits["fast"],
                     "visited_bytes_per_ray": round(b_ray_visited, 1), "visited_achieved": round(contract_visited, 2)}
-        pmc, pmc_note = (load_pmc("c2") if (c2 and single) else (None, "PMC passes exist for the C2 workload on one GPU only"))
+        pmc, pmc_note = (load_pmc(wl) if (wl in ("c2", "c3") and single) else (None, "PMC passes exist for the C2 / C3 workloads on one GPU only"))
         if pmc is not None:
-            bounds = bounds_from_pmc(pmc, k_ms * 1e-3, load_census("c2"))
+            bounds = bounds_from_pmc(pmc, k_ms * 1e-3, load_census(wl))
             roofline["bounds"] = bounds
             if bounds:
                 name = max(bounds, key=lambda b: bounds[b]["frac"])
@@ -421,8 +459,11 @@ def main_rank(args):
                                "salu_per_valu": pmc.get("salu_per_valu"), "wait_any_frac": pmc.get("SQ_WAIT_ANY/WAVE_CYCLES"),
                                "tcc_miss_frac": pmc.get("tcc_miss_frac")}
             roofline["note"] = ("counts from rocprofv3 --pmc passes of this exact workload and code (hash-stamped), time from HIP events of this "
-                                "run; the largest of the three fractions names the bound; the scene is cache resident and the kernel is "
-                                "latency bound (SQ_WAIT_ANY), see DESIGN.md")
+                                "run; every fraction is against a datasheet peak (MI355X_MICROARCH.md) and the largest names the bound.  The "
+                                "kernel is co-limited: its vector pipes are `bounds.valu_issue.valu_busy_hw` busy (the hardware's counter) "
+                                "executing an opcode mix that costs `mix_cycles_per_instr` cycles per instruction instead of the guide's 2, "
+                                "`arith_share` of those instructions are box / triangle arithmetic; its waves wait on memory `pmc.wait_any_frac` "
+                                "of their cycles (DESIGN.md section 5)")
         else:
             roofline["note"] = pmc_note
 
@@ -518,6 +559,67 @@ def main_rank(args):
                 c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3, load_census("c3"))
             r3.free()
 
+        # ---- the mesh-size cliff: the stand-in's leaf records fit the 16-bit stack entries of the coupled pool; a mesh of the
+        #      reference's real size does not and renders with the decoupled-leaves pool.  Timed here: the stand-in under that layout
+        #      (CRT_REF16=0: "the leaf records do not fit"), under the coupled pool's 32-bit layout (what such a mesh got in rounds 1-3), and a
+        #      102 412-triangle variant of the scene (scenes/gen_cornell_box.py --detail 6,5), same camera, same spp ----
+        large = None
+        if single and c2 and not multi and not args.no_large_scene:
+            def timed_frames(rr, n=3):
+                render_sharded(rr, eye, inv_view, fov, args.width, args.height, 0, 1, device)
+                torch.cuda.synchronize(device)
+                c0_ = time.perf_counter()
+                ks = []
+                for _ in range(n):
+                    _, st_ = render_sharded(rr, eye, inv_view, fov, args.width, args.height, 0, 1, device)
+                    ks.append(st_["kernel_ms"])
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - c0_) * 1e3 / n, float(np.mean(ks)), st_
+
+            def with_env(env, fn):
+                old = {k: os.environ.get(k) for k in ("CRT_DEC", "CRT_REF16", "CRT_REF32")}
+                for k in old:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                try:
+                    return fn()
+                finally:
+                    for k, v in old.items():
+                        os.environ.pop(k, None)
+                        if v is not None:
+                            os.environ[k] = v
+            render.set_spp(args.spp)
+            render.traversal = trav
+            ms_large_layout, k_large_layout, _ = with_env({"CRT_REF16": "0"}, lambda: timed_frames(render))
+            ms_coupled32, k_coupled32, _ = with_env({"CRT_DEC": "0", "CRT_REF16": "0"}, lambda: timed_frames(render))
+            ms_default, k_default, _ = with_env({}, lambda: timed_frames(render))
+            import tempfile
+            sys.path.insert(0, os.path.join(ROOT, "scenes"))
+            import gen_cornell_box
+            with tempfile.TemporaryDirectory() as td:
+                obj_l, mtl_l, n_tri_l = gen_cornell_box.write_variant(td, (6, 5))
+                sl = crt.Scene(args.width, args.height)
+                sl.add_obj(obj_l, mtl_l)
+                sl.set_BVH(task.bvh_thresh_n)
+                rl = crt.Render(sl, args.spp, task.P_RR, task.light_sample_n, device=local_rank)
+                rl.seed = args.seed
+                rl.traversal = trav
+                ai_l = rl.accel_info()
+                ms_l, k_l, st_l = with_env({}, lambda: timed_frames(rl))
+                ms_l32, k_l32, _ = with_env({"CRT_DEC": "0"}, lambda: timed_frames(rl))
+                rl.free()
+            large = {"standin_default_layout_ms": round(ms_default, 3), "standin_large_mesh_layout_ms": round(ms_large_layout, 3),
+                     "standin_large_mesh_layout_over_default": round(ms_large_layout / ms_default, 4),
+                     "standin_coupled_32bit_layout_ms": round(ms_coupled32, 3),
+                     "layouts": "default: coupled pool, eight 16-bit stack levels in LDS (node and leaf refs < 32 768); large-mesh: decoupled leaves, "
+                                "six 16-bit levels of inner nodes (four-wide nodes < 32 768, any number of leaves: CRT_REF16=0 forces it on the stand-in); "
+                                "coupled 32-bit: four LDS levels (what a larger mesh rendered with in rounds 1-3)",
+                     "large_scene": {"workload": "cornell-box --detail 6,5: %d triangles, %d leaf records, %d four-wide nodes, %dx%d spp=%d"
+                                                 % (n_tri_l, ai_l["n_leaves"], ai_l["n_nodes4"], args.width, args.height, args.spp),
+                                     "layout_caps": ai_l["layout_caps"], "ms_per_frame": round(ms_l, 3), "kernel_ms": round(k_l, 3),
+                                     "rays_per_frame": int(st_l["rays"]), "mrays_per_sec": round(st_l["rays"] / ms_l / 1e3, 2),
+                                     "coupled_32bit_layout_ms": round(ms_l32, 3)}}
+
         # ---- CPU baseline + same-run parity gate: the oracle renders the 800x600 spp=--cpu-spp frame on one host
         #      thread; the GPU renders the same frame; every pixel is compared ----
         cpu = None
@@ -575,6 +677,7 @@ def main_rank(args):
                                            % (100.0 * untraced_local / max(1, rays_local), "" if multi else " on rank 0")},
             "frames_per_sec": round(1e3 / ms_per_step, 4),
             "frames_in_flight": 2 if pipelined else 1,
+            "frames_without_kernel_time": kernel_ms_missing,
             "frame_latency_ms": round(frame_latency_ms, 3) if frame_latency_ms is not None else round(ms_per_step, 3),
             "rays_per_frame": int(rays_frame),
             "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
@@ -583,7 +686,11 @@ def main_rank(args):
                            "rccl_ranks": rccl_ranks,
                            "launched_by": "torch.distributed.run" if (world > 1 and not os.environ.get("CRT_BENCH_SPAWNED")) else
                                           ("bench.py (self-started ranks)" if world > 1 else "single process")},
-            "build_flags": B.built_flags(),
+            "build_flags": B.built_flags() if not os.environ.get("CRT_LIB_PATH") else "unknown (CRT_LIB_PATH)",
+            "library": os.environ.get("CRT_LIB_PATH") or "in-tree cudaraytracing_amd/lib/libcrt.so",
+            "src_hash": B.source_hash() if not os.environ.get("CRT_LIB_PATH") else None,
+            "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("CRT_")},
+            "workload_id": wl,
             "radiance_storage": radiance_storage,
             "scene_setup": setup,
             "rays_untraced_per_frame_rank0": int(untraced_local),
@@ -608,10 +715,11 @@ def main_rank(args):
                                 "kernel_ms_mean": round(float(np.mean(rank_kernel_ms)), 3), "kernel_ms": [round(v, 3) for v in rank_kernel_ms],
                                 "non_kernel_ms_per_step": round(ms_per_step - max(rank_kernel_ms), 3)}
             try:
-                sm = json.load(open(os.path.join(ROOT, "profiles", "share_model.json")))
-                if c2 and sm.get("workload") == "c2":
+                sm = json.load(open(os.path.join(ROOT, "profiles", "share_model.json"))).get("workloads", {}).get(wl)
+                if sm:
                     line["per_rank"]["predicted_share_ms"] = round(sm["tail_ms"] + (sm["one_gpu_kernel_ms"] - sm["tail_ms"]) / n_gpus, 3)
                     line["per_rank"]["predicted_share_model"] = sm.get("note")
+                    line["per_rank"]["measured_share_on_one_gpu_ms"] = sm.get("measured_share_kernel_ms", {}).get(str(n_gpus))
             except Exception:
                 pass
         if multi:
@@ -620,6 +728,8 @@ def main_rank(args):
             line["parity"] = parity
         if c3 is not None:
             line["c3"] = c3
+        if large is not None:
+            line["mesh_size"] = large
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

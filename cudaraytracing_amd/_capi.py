@@ -8,6 +8,7 @@ import numpy as np
 from . import build as _build
 
 CRT_OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP = -1, -2, -3   # include/crt.h: crt_status
 TRAVERSAL_EXACT = 0      # the default: provably the reference's frame
 TRAVERSAL_REFERENCE = 1
 TRAVERSAL_FAST = 2       # + distance pruning (measured rate of lost rays, include/crt.h)
@@ -96,7 +97,7 @@ class BvhBuildInfo(C.Structure):
 
 class AccelInfo(C.Structure):
     _fields_ = [("n_leaves", C.c_uint32), ("n_nodes2", C.c_uint32), ("n_nodes4", C.c_uint32), ("depth2", C.c_uint32), ("depth4", C.c_uint32),
-                ("sah_on_device", C.c_uint32), ("index_splits", C.c_uint32), ("sah_ms", C.c_float), ("sah_device_ms", C.c_float)]
+                ("sah_on_device", C.c_uint32), ("index_splits", C.c_uint32), ("sah_ms", C.c_float), ("sah_device_ms", C.c_float), ("runtime_init_ms", C.c_float), ("layout_caps", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -115,7 +116,7 @@ TRI_DTYPE = np.dtype([("v1", "<f4", 3), ("v2", "<f4", 3), ("v3", "<f4", 3), ("no
 MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3), ("ns", "<f4"), ("mode", "<i4"), ("has_emit", "<i4")])
 LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
-ABI_VERSION = 3  # include/crt.h: CRT_ABI_VERSION
+ABI_VERSION = 4  # include/crt.h: CRT_ABI_VERSION
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",

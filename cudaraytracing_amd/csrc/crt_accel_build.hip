@@ -248,6 +248,14 @@ int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, i
     nodes.clear();
     const int n = (int)prims.size();
     if (n == 1) { root_ref = prims[0].ref; return 1; }
+    const bool timing = std::getenv("CRT_SAH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_sec = now();
+    auto section = [&](const char* what) {
+        if (timing) { std::fprintf(stderr, "[sah] %-10s %8.3f ms\n", what, ms_since(t_sec)); }
+        t_sec = now();
+    };
     try {
         std::vector<float4> lo(n), hi(n);
         for (int i = 0; i < n; i++) {
@@ -256,12 +264,14 @@ int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, i
             lo[i] = make_float4(prims[i].box.lo[0], prims[i].box.lo[1], prims[i].box.lo[2], rf);
             hi[i] = make_float4(prims[i].box.hi[0], prims[i].box.hi[1], prims[i].box.hi[2], 0.0f);
         }
+        section("pack");
         ABuf<float4> d_lo, d_hi;
         ABuf<uint32_t> d_order[2], d_cnt; // d_cnt: [0], [1] ranges of the two level buffers, [2] tmp nodes, [3] depth, [4] splits by index
         ABuf<DSeg> d_segs[2];
         ABuf<DTmp> d_tmp;
         d_lo.alloc(n); d_hi.alloc(n); d_order[0].alloc(n); d_order[1].alloc(n); d_cnt.alloc(5);
         d_segs[0].alloc(n); d_segs[1].alloc(n); d_tmp.alloc(n);
+        section("alloc");
         AHIP(hipMemcpy(d_lo.p, lo.data(), (size_t)n * 16, hipMemcpyHostToDevice));
         AHIP(hipMemcpy(d_hi.p, hi.data(), (size_t)n * 16, hipMemcpyHostToDevice));
         {
@@ -274,6 +284,7 @@ int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, i
             const uint32_t init[5] = {1u /* segments of level 0 */, 0u, 1u /* tmp nodes */, 1u /* depth */, 0u};
             AHIP(hipMemcpy(d_cnt.p, init, sizeof(init), hipMemcpyHostToDevice));
         }
+        section("upload");
         hipEvent_t e0, e1;
         AHIP(hipEventCreate(&e0)); AHIP(hipEventCreate(&e1));
         AHIP(hipEventRecord(e0, nullptr));
@@ -293,6 +304,7 @@ int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, i
         }
         AHIP(hipEventRecord(e1, nullptr));
         AHIP(hipDeviceSynchronize());
+        section("levels");
         if (device_ms) AHIP(hipEventElapsedTime(device_ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         uint32_t fin[5];
@@ -320,6 +332,7 @@ int build_sah_device(const std::vector<Prim>& prims, std::vector<Node>& nodes, i
             }
         }
         root_ref = 0;
+        section("download");
         return (int)fin[3];
     } catch (const AErr&) {
         (void)hipGetLastError();

@@ -778,7 +778,18 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
     try {
         sc = new crt_scene();
         sc->device = device;
-        HIP_CHECK(hipSetDevice(device));
+        {
+            // the HIP runtime starts with the first call that needs the device (context, the library's code objects): timed by itself
+            // so that it is not booked on whatever happens to come first (it was the SAH build's first upload: "147 ms" of tree building)
+            const auto t0 = std::chrono::steady_clock::now();
+            HIP_CHECK(hipSetDevice(device));
+            void* warm = nullptr;
+            const uint32_t zero = 0;
+            HIP_CHECK(hipMalloc(&warm, 4));
+            HIP_CHECK(hipMemcpy(warm, &zero, 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipFree(warm));
+            sc->accel.runtime_init_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         std::vector<float4> nodes, geo(d->n_tris * 3ull), mats(d->n_materials * 3ull), ltri(d->n_light_tris * 4ull);
         std::vector<int32_t> leaf_count, tri_mat(d->n_tris);
         int32_t root_fast = 0, root_exact = 0;
@@ -1010,6 +1021,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->ref16_ok = n_nodes4 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
         sc->ref16_inner_ok = n_nodes4 <= 32768;
         sc->dec_ok = leaf_geo.size() / 5 <= (size_t)LEAF_REC_MAX + 1;
+        sc->accel.layout_caps = (sc->ref16_ok ? 1u : 0u) | (sc->ref16_inner_ok ? 2u : 0u) | (sc->dec_ok ? 4u : 0u);
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);

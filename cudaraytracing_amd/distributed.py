@@ -128,6 +128,7 @@ class FramePipeline:
         self.next = 0
         self.done = []
         self.kernel_ms = []
+        self.kernel_ms_missing = 0   # frames of the fallback pipeline (no megakernel launch to time)
 
     def _retire(self, h):
         if self.pending[h] is not None:
@@ -137,10 +138,17 @@ class FramePipeline:
             if self.ready[h] is not None:
                 self.ready[h].synchronize()
             self.streams[h].synchronize()
+            from ._capi import CrtError, ERR_INVALID_ARG
             try:
                 ms, _ = self.renders[h].last_launch_ms()
-            except Exception:   # the wavefront fallback pipeline records no megakernel launch
+            except CrtError as e:
+                # the one expected failure: the wavefront fallback pipeline records no megakernel launch (CRT_ERR_INVALID_ARG,
+                # "no frame has been rendered by the megakernel"); anything else -- a HIP error of an unsynchronised stream or a
+                # faulted device -- is a real error and is raised
+                if e.status != ERR_INVALID_ARG or "no frame has been rendered by the megakernel" not in str(e):
+                    raise
                 ms = None
+                self.kernel_ms_missing += 1
             self.kernel_ms.append(ms)
             self.done.append(self.pending[h])
             self.pending[h] = None

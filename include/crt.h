@@ -28,7 +28,7 @@ extern "C" {
  *    argument carries flag bits (CRT_INTERSECT_RAW_DIRECTIONS 0x100, _FORCE_EXACT 0x200, _VISIBILITY 0x400), progressive /
  *    preview / multi-device / accel-info entry points and structs added.  A client built against version 2 must be rebuilt:
  *    check crt_abi_version() == CRT_ABI_VERSION at load time. */
-#define CRT_ABI_VERSION 3
+#define CRT_ABI_VERSION 4
 
 typedef enum {
     CRT_OK = 0,
@@ -191,6 +191,13 @@ typedef struct {
                                  device builder's tree may differ from the host builder's (equal leaves on different sides) */
     float sah_ms;             /* host clock: the whole SAH build (uploads and renumbering included) */
     float sah_device_ms;      /* HIP events around the level loop (0 for the host builder) */
+    float runtime_init_ms;    /* host clock of crt_scene_create's first device calls (hipSetDevice, a 4-byte allocation and copy): the HIP
+                                 runtime's one-off start in a process -- context creation, loading libcrt.so's code objects; about 150 ms
+                                 for the first scene of a process, microseconds afterwards.  Not part of sah_ms. */
+    uint32_t layout_caps;     /* which pool layouts of the render kernel the scene allows: bit 0 = node AND leaf refs fit 16-bit stack
+                                 entries (coupled form, 8 LDS levels), bit 1 = the four-wide nodes alone do (decoupled leaves, 6 levels:
+                                 what a scene of roughly 50 000 - 160 000 triangles renders with), bit 2 = leaf records fit a leaf-queue
+                                 entry (decoupled leaves possible at all) */
 } crt_accel_info;
 int crt_scene_accel_info(crt_scene* scene, crt_accel_info* out);
 /* replaces Render::free (Render.cuh:477-487) */

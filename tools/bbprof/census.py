@@ -41,11 +41,21 @@ def main():
         open(os.path.join(a.run, wl + "_report.txt"), "w").write(txt)
         r = json.load(open(tmp))
         scale = spp_full / float(spp_run)
+        # what the vector instructions are: intersection arithmetic (the box and triangle tests with their reciprocals, minima and
+        # maxima), the rest of the two traversal steps (rings, records, stacks, routing), the path logic
+        ARITH = ("tri_pair", "slab_quad_pruned", "slab_pair", "slab_pair_pruned", "rcp_short", "rcp_short_ok", "rcp_short_ok2", "rcp_short_ok3", "rcp_ieee",
+                 "inv3_exact", "fmin3", "fmax3", "finite3")
+        trav = ("inner", "leaf", "inner_ex", "leaf_ex")
+        arith = sum(e["dyn_valu"] for e in r["by_phase_function"] if e["phase"] in trav and e["function"] in ARITH)
+        trav_all = sum(e["dyn_valu"] for e in r["by_phase_function"] if e["phase"] in trav) + r["by_phase"].get("other", {}).get("dyn_valu", 0)
         out["workloads"][wl] = {
             "profiled": "%s spp=%d (one launch), scaled x%g to spp=%d" % (what, spp_run, scale, spp_full), "kernel": r["kernel"],
             "valu_instructions_per_launch": r["dyn_valu"] * scale, "lane_utilisation": r["lane_utilisation"],
             "cycles_per_valu": r["cycles_per_valu"]["mid"], "cycles_per_valu_range": [r["cycles_per_valu"]["lo"], r["cycles_per_valu"]["hi"]],
             "unpriced_share": r["cycles_per_valu"]["unpriced_share"], "tiers": r["cycles_per_valu"]["tiers"],
+            "arith_share": arith / r["dyn_valu"], "traversal_bookkeeping_share": (trav_all - arith) / r["dyn_valu"],
+            "path_logic_share": 1.0 - trav_all / r["dyn_valu"],
+            "arith_functions": list(ARITH),
             "instructions_per_launch_by_kind": {k: v * scale for k, v in r["kinds"].items()},
             "by_phase": {ph: {"valu_share": v["dyn_valu"] / r["dyn_valu"], "lanes": v["lanes"]} for ph, v in r["by_phase"].items() if v["dyn_valu"] > 0.0005 * r["dyn_valu"]}}
     json.dump(out, open(a.out, "w"), indent=1)

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 timeout -k 10 1000 python3 -m pytest tests -m gpu -q "$@" > gpurun_out/${tag}_tests.log 2>&1
 rc=$?
 tail -5 gpurun_out/${tag}_tests.log
-[ $rc -le 1 ] || { echo "pytest rc=$rc: stopping"; exit $rc; }
+[ $rc -eq 0 ] || { echo "pytest rc=$rc: stopping"; exit $rc; }
 hipcc -O2 --offload-arch=gfx950 tools/valu_issue_bench.hip -o /tmp/valu_issue_bench && timeout -k 10 120 /tmp/valu_issue_bench > gpurun_out/${tag}_valu_issue.json || { echo "valu bench failed"; exit 3; }
 timeout -k 10 400 python3 bench.py > gpurun_out/${tag}_bench.log 2>&1 || { echo "bench failed"; tail -20 gpurun_out/${tag}_bench.log; exit 4; }
 tail -1 gpurun_out/${tag}_bench.log
