@@ -24,7 +24,7 @@ for wl, r in sorted(rows.items()):
     # share - t1 / N = tail (1 - 1 / N)
     num = sum((r[n]["kernel_ms"] - t1 / n) * (1.0 - 1.0 / n) for n in r if n > 1)
     den = sum((1.0 - 1.0 / n) ** 2 for n in r if n > 1)
-    tail = num / den if den else 0.0
+    tail = max(0.0, num / den) if den else 0.0   # (a frame of several launches on one GPU pays several tails: the fit can come out slightly negative)
     out["workloads"][wl] = {"workload": "%s %dx%d spp=%d" % (r[1]["scene"], r[1]["width"], r[1]["height"], r[1]["spp"]),
                             "one_gpu_kernel_ms": t1, "launches_per_frame_on_one_gpu": r[1].get("launches"), "tail_ms": round(tail, 3),
                             "measured_share_kernel_ms": {str(n): r[n]["kernel_ms"] for n in sorted(r)},
