@@ -145,7 +145,11 @@ struct Pool4LdsT {
     static constexpr int P = RING_ ? 148 : 152;
 #endif
     static constexpr int QCAP = (P + 3) & ~3;
+#ifdef POOL4_LV
+    static constexpr int LV = R16_ ? POOL4_LV : POOL4_LV / 2;
+#else
     static constexpr int LV = R16_ ? 6 : 3;
+#endif
     typedef typename std::conditional<R16_, short, int>::type stk_t;
     float4 A[P];                 // origin.xyz, the distance an accepted hit must stay below by more than EPSILON: the light's for an any-hit ray, +inf otherwise
     float4 B[P];                 // direction.xyz, bits(current node ref)

@@ -724,15 +724,20 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     const float inf = pinf();
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
-    const bool l0 = (t0 < inf) & (r0 < 0), l1 = (t1 < inf) & (r1 < 0), l2 = (t2 < inf) & (r2 < 0), l3 = (t3 < inf) & (r3 < 0);
-#define CRT_LEAF_MASK(t_, r_) (__builtin_amdgcn_ballot_w64(t_ < inf) & __builtin_amdgcn_ballot_w64(r_ < 0))
-    leafq_push(S, id, l0, CRT_LEAF_MASK(t0, r0), ((uint32_t)r0 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l1, CRT_LEAF_MASK(t1, r1), ((uint32_t)r1 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l2, CRT_LEAF_MASK(t2, r2), ((uint32_t)r2 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l3, CRT_LEAF_MASK(t3, r3), ((uint32_t)r3 & 0x7fffff00u) | id, lq_t, added);
+    // (one compare per operand, shared by the lane's predicate and the wave's mask: the mask is the AND of the two ballots)
+    // (t is an entry distance of finite operands or exactly +inf, never a NaN: the integer compare is the same test, and one the
+    // compiler does not rewrite differently for the predicate and for the ballot)
+    const bool h0 = __float_as_uint(t0) != 0x7f800000u, h1 = __float_as_uint(t1) != 0x7f800000u, h2 = __float_as_uint(t2) != 0x7f800000u, h3 = __float_as_uint(t3) != 0x7f800000u;
+    const bool n0 = r0 < 0, n1 = r1 < 0, n2 = r2 < 0, n3 = r3 < 0;
+    const bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
+#define CRT_LEAF_MASK(h_, n_) (__builtin_amdgcn_ballot_w64(h_) & __builtin_amdgcn_ballot_w64(n_))
+    leafq_push(S, id, l0, CRT_LEAF_MASK(h0, n0), ((uint32_t)r0 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l1, CRT_LEAF_MASK(h1, n1), ((uint32_t)r1 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l2, CRT_LEAF_MASK(h2, n2), ((uint32_t)r2 & 0x7fffff00u) | id, lq_t, added);
+    leafq_push(S, id, l3, CRT_LEAF_MASK(h3, n3), ((uint32_t)r3 & 0x7fffff00u) | id, lq_t, added);
 #undef CRT_LEAF_MASK
     any_leaf = l0 | l1 | l2 | l3;
-    t0 = r0 < 0 ? inf : t0; t1 = r1 < 0 ? inf : t1; t2 = r2 < 0 ? inf : t2; t3 = r3 < 0 ? inf : t3;
+    t0 = n0 ? inf : t0; t1 = n1 ? inf : t1; t2 = n2 ? inf : t2; t3 = n3 ? inf : t3;
 #define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
 #ifndef CRT_DEC_UNSORTED
     CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2)
@@ -829,6 +834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #pragma unroll
     for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; qt[p] = 0; }
     uint32_t dg_b[5] = {0, 0, 0, 0, 0}, dg_l[5] = {0, 0, 0, 0, 0}; // STATS: batches and rays per phase
+    uint32_t dg_sp[6] = {0, 0, 0, 0, 0, 0};                         // STATS, per lane: inner steps that leave the stack deeper than 1 .. 6 entries
     uint32_t lq_h = 0, lq_t = 0; // DEC: the leaf queue's head and tail, free-running (entries = tail - head, index = counter mod LEAFQ_CAP)
     constexpr bool commit_ring = RING;
     if (commit_ring && lane == 0) S.waitq = 0u;
@@ -903,7 +909,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             const int kC = min(qn[PH3_LC], 64) * 8 + PH3_LC, kA = min(qn[PH3_LA], 64) * 8 + PH3_LA, kB = min(qn[PH3_LB], 64) * 8 + PH3_LB;
             // (DEC: the leaf queue counts entries, not rays; with 64 or more it is the fullest there can be and wins over the inner ring,
             // so an inner batch always finds room for 4 entries per ray of at least 48 rays)
-            const int kL = min(DEC ? (int)(lq_t - lq_h) : qn[PH3_LEAF], 64) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
+#ifndef LEAFQ_FIRST
+#define LEAFQ_FIRST 48 /* DEC: with this many entries the leaf queue goes before everything else -- at 64 an inner batch is cut to (256 - entries) / 4 = 48 .. 64
+                          rays (measured fill 55); from 48 on the queue is emptied earlier, the inner batches find room for 52 and more (C2 93.9 -> 92.1 ms,
+                          veach-mis spp 256 90.6 -> 89.4; 40 / 56 / 32: 91.9 / 92.9 / 92.0 and 89.6 / 89.5 / 90.8) */
+#endif
+            const int nl_ = DEC ? (int)(lq_t - lq_h) : qn[PH3_LEAF];
+            const int kL = ((DEC && nl_ >= LEAFQ_FIRST) ? 64 : min(nl_, 64)) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
             // (s_max_i32 by hand: the compiler folds nested maxima of wave-uniform values into v_max3_i32 -- a vector instruction, plus
             // two moves in and a v_readfirstlane back)
             const int best = STATS ? max(max(max(kC, kA), max(kB, kL)), kI) // (the counting kernels keep more scalars: theirs may live in vector registers)
@@ -950,6 +962,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 }
                 S.node[id] = ref;
                 S.D[id] = (qd & ~0xffu) | (uint32_t)sp;
+                if (STATS) { for (int k = 0; k < 6; k++) dg_sp[k] += sp > k + 1 ? 1u : 0u; }
                 if (STATS && done && (qd & RF_HASHIT)) tc.hits++; // (an any-hit ray that records a hit ends in the leaf step)
                 t_done = done; t_ref = ref; t_flags = qd;
             }
@@ -1090,6 +1103,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 }
                 // the record: node, stack depth, "the walk is over" -- the count of entries in flight in between is touched by atomics only
                 // (leafq_push above: those additions are in LDS before this one, same wave, in order)
+                if (STATS) { for (int k = 0; k < 6; k++) dg_sp[k] += sp > k + 1 ? 1u : 0u; }
                 S.B[id].w = __int_as_float(ref);
                 __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (done ? RD_FIN : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool comp = done & !any_leaf & ((qd & RD_PEND_MASK) == 0u);
@@ -1314,6 +1328,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 atomicAdd(&cs[C_DIAG + 2 * p], (unsigned long long)dg_b[p]);
                 atomicAdd(&cs[C_DIAG + 2 * p + 1], (unsigned long long)dg_l[p]);
             }
+        }
+        for (int k = 0; k < 6; k++) {
+            const uint32_t v = wave_sum(dg_sp[k]);
+            if (lane == 0) atomicAdd(&cs[C_DIAG + 10 + k], (unsigned long long)v);
         }
     }
 }

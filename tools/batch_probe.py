@@ -22,6 +22,7 @@ out = {"scene": a.scene, "env": {k: v for k, v in os.environ.items() if k.starts
        "inner_per_ray": round(s["inner_pops"] / traced, 3), "leaf_per_ray": round(s["leaf_pops"] / traced, 3),
        "batches": {n: pc[2 * i] for i, n in enumerate(names)},
        "fill": {n: round(pc[2 * i + 1] / max(1, pc[2 * i]), 2) for i, n in enumerate(names)},
+       "stack_deeper_than": {str(k + 1): round(s["phase_cycles"][14 + k] / max(1, s["inner_pops"]), 4) for k in range(6)}, "stack_max": s["stack_max"],
        "stats_kernel_ms": round(s["kernel_ms"], 2)}
 ms = []
 for i in range(3):
