@@ -120,7 +120,7 @@ ABI_VERSION = 4  # include/crt.h: CRT_ABI_VERSION
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",
-           "crt_scene_accel_info", "crt_scene_destroy", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_radiance_storage", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
+           "crt_scene_accel_info", "crt_scene_destroy", "crt_task_obj", "crt_shard_slots", "crt_render", "crt_render_device", "crt_render_range", "crt_render_range_device", "crt_last_launch_ms", "crt_radiance_storage", "crt_preview", "crt_preview_device", "crt_multi_create", "crt_multi_destroy",
            "crt_multi_render", "crt_multi_frame_device", "crt_intersect",
            "crt_device_math", "crt_device_philox", "crt_device_rcp_check", "crt_host_scene_create", "crt_host_scene_destroy",
            "crt_host_scene_add_obj", "crt_host_scene_set_bvh", "crt_host_scene_set_bvh_device", "crt_host_scene_desc", "crt_host_scene_num_objects",
@@ -182,6 +182,7 @@ def lib():
                                         C.POINTER(C.c_uint32)]
     L.crt_inverse_view.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.crt_task_load.argtypes = [C.c_char_p, C.POINTER(Task)]
+    L.crt_task_obj.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32]
     L.crt_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_uint64]
     L.crt_write_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
     _lib = L

@@ -42,7 +42,14 @@ class Task:
             p = p.decode()
             return p if os.path.isabs(p) else os.path.join(base, p)
 
-        self.OBJ_paths = [(res(t.obj_path[i].value), res(t.mtl_dir[i].value)) for i in range(t.n_objs)]
+        if t.n_objs <= 8:
+            self.OBJ_paths = [(res(t.obj_path[i].value), res(t.mtl_dir[i].value)) for i in range(t.n_objs)]
+        else:   # (any number of OBJ files, as src/main.cu:74-78 loops over them: the POD holds eight, crt_task_obj returns each)
+            self.OBJ_paths = []
+            for i in range(t.n_objs):
+                o, m = C.create_string_buffer(4096), C.create_string_buffer(4096)
+                capi.check(capi.lib().crt_task_obj(os.fsencode(config_path), i, o, m, 4096), "crt_task_obj")
+                self.OBJ_paths.append((res(o.value), res(m.value)))
         self.lookat = np.array(t.lookat[:], dtype=np.float32)
         self.up = np.array(t.up[:], dtype=np.float32)
         self.eye_pos = np.array(t.eye_pos[:], dtype=np.float32)

@@ -28,7 +28,8 @@ int main(int argc, char** argv)
         return 2;
     }
     try {
-        crt_task task = crt::load_task(argv[1]);
+        crt::TaskObjs all_objs;
+        crt_task task = crt::load_task(argv[1], &all_objs);
         std::string out = "out.png", base_dir = ".";
         uint64_t seed = 0;
         int device = 0;
@@ -80,7 +81,7 @@ int main(int argc, char** argv)
             } else throw crt::Error(CRT_ERR_INVALID_ARG, "unknown option " + a);
         }
         crt::Scene scene(task.width, task.height);
-        crt::load_task_scene(task, scene, base_dir);
+        crt::load_task_scene(task, scene, base_dir, &all_objs);
         scene.set_BVH(task.bvh_thresh_n);
         std::printf("triangles: %zu, BVH nodes: %zu, lights: %zu\n", scene.get_triangles().size(), scene.get_bvh().get_nodes_size(),
                     scene.get_light_objs().size());

@@ -537,7 +537,7 @@ void copy_path(char (&dst)[512], const std::string& src)
 } // namespace
 
 // reference: src/main.cu:67-90
-crt_task load_task(const std::string& config_path)
+crt_task load_task(const std::string& config_path, TaskObjs* all_objs)
 {
     std::ifstream f(config_path);
     if (!f.is_open()) throw Error(CRT_ERR_IO, "unable to open config: " + config_path);
@@ -551,11 +551,13 @@ crt_task load_task(const std::string& config_path)
     std::memset(&t, 0, sizeof(t));
     const JValue& objs = j.at("OBJ_paths");
     if (objs.kind != JValue::ARR || objs.arr.empty()) throw Error(CRT_ERR_PARSE, "config: OBJ_paths must be a non-empty array");
-    if (objs.arr.size() > 8) throw Error(CRT_ERR_UNSUPPORTED, "config: more than 8 OBJ files");
     t.n_objs = (uint32_t)objs.arr.size();
+    if (all_objs) all_objs->clear();
     for (uint32_t i = 0; i < t.n_objs; i++) {
-        copy_path(t.obj_path[i], objs.arr[i].at("OBJ_path").str);
-        copy_path(t.mtl_dir[i], objs.arr[i].at("MTL_dir").str);
+        const std::string& o = objs.arr[i].at("OBJ_path").str;
+        const std::string& m = objs.arr[i].at("MTL_dir").str;
+        if (i < 8) { copy_path(t.obj_path[i], o); copy_path(t.mtl_dir[i], m); }   // (the POD's slots; the rest through all_objs / crt_task_obj)
+        if (all_objs) all_objs->push_back(std::make_pair(o, m));
     }
     auto vec = [&](const char* key, float out[3]) {
         const JValue& v = j.at(key);
@@ -575,8 +577,10 @@ crt_task load_task(const std::string& config_path)
 }
 
 // reference: src/main.cu:122-145
-void load_task_scene(const crt_task& task, Scene& scene, const std::string& base_dir)
+void load_task_scene(const crt_task& task, Scene& scene, const std::string& base_dir, const TaskObjs* all_objs)
 {
+    if (task.n_objs > 8 && (!all_objs || all_objs->size() != task.n_objs))
+        throw Error(CRT_ERR_INVALID_ARG, "load_task_scene: a task of more than 8 OBJ files needs the list load_task returns");
     auto resolve = [&](const char* p) {
         std::string s(p);
         if (!s.empty() && s[0] == '/') return s;
@@ -584,7 +588,7 @@ void load_task_scene(const crt_task& task, Scene& scene, const std::string& base
     };
     for (uint32_t i = 0; i < task.n_objs; i++) {
         Loader loader;
-        std::string obj = resolve(task.obj_path[i]), mtl = resolve(task.mtl_dir[i]);
+        std::string obj = resolve(all_objs ? (*all_objs)[i].first.c_str() : task.obj_path[i]), mtl = resolve(all_objs ? (*all_objs)[i].second.c_str() : task.mtl_dir[i]);
         loader.read_OBJ(obj.c_str(), mtl.c_str());
         std::vector<Triangle> tris, light_tris;
         for (uint64_t s = 0; s < loader.size(); s++) {
@@ -796,6 +800,18 @@ int crt_task_load(const char* path, crt_task* out)
 {
     if (!path || !out) { g_last_error = "crt_task_load: null argument"; return CRT_ERR_INVALID_ARG; }
     CRT_HOST_TRY(*out = crt::load_task(path));
+}
+int crt_task_obj(const char* path, uint32_t index, char* obj_path, char* mtl_dir, uint32_t cap)
+{
+    if (!path || !obj_path || !mtl_dir) { g_last_error = "crt_task_obj: null argument"; return CRT_ERR_INVALID_ARG; }
+    CRT_HOST_TRY({
+        crt::TaskObjs all;
+        (void)crt::load_task(path, &all);
+        if (index >= all.size()) throw crt::Error(CRT_ERR_INVALID_ARG, "crt_task_obj: index beyond the file's OBJ_paths");
+        if (all[index].first.size() + 1 > cap || all[index].second.size() + 1 > cap) throw crt::Error(CRT_ERR_INVALID_ARG, "crt_task_obj: buffer too small");
+        std::memcpy(obj_path, all[index].first.c_str(), all[index].first.size() + 1);
+        std::memcpy(mtl_dir, all[index].second.c_str(), all[index].second.size() + 1);
+    });
 }
 
 // ---- PNG (stored deflate blocks; replaces stbi_write_png, Render.cuh:489-493) ----

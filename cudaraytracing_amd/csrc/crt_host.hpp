@@ -196,10 +196,12 @@ private:
 // reference: include/Camera.h:9-36; out is column-major
 void get_inverse_view_matrix(const float eye[3], const float lookat[3], const float up[3], float out[9]);
 
-// reference: src/main.cu:40-90
-crt_task load_task(const std::string& config_path);
-// loads every OBJ of a task into `scene` the way render_view does (src/main.cu:122-145)
-void load_task_scene(const crt_task& task, Scene& scene, const std::string& base_dir);
+// reference: src/main.cu:40-90.  all_objs (optional): every (OBJ_path, MTL_dir) pair of the file -- the crt_task POD holds the first eight
+typedef std::vector<std::pair<std::string, std::string>> TaskObjs;
+crt_task load_task(const std::string& config_path, TaskObjs* all_objs = nullptr);
+// loads every OBJ of a task into `scene` the way render_view does (src/main.cu:122-145); all_objs as returned by load_task when the
+// file names more than eight
+void load_task_scene(const crt_task& task, Scene& scene, const std::string& base_dir, const TaskObjs* all_objs = nullptr);
 
 // reference: include/Render.cuh:357-557.  Drives the device layer through the C ABI.
 class Render {

@@ -358,8 +358,8 @@ int crt_inverse_view(const float eye[3], const float lookat[3], const float up[3
 
 /* Task / config.json (src/main.cu:40-90) */
 typedef struct {
-    uint32_t n_objs;
-    char obj_path[8][512];
+    uint32_t n_objs;           /* entries of OBJ_paths in the file -- any number, as src/main.cu:74-78 loops over them */
+    char obj_path[8][512];     /* the first eight; crt_task_obj() returns any of them */
     char mtl_dir[8][512];
     float lookat[3], up[3], eye_pos[3];
     float fov_y;        /* degrees, as in the file */
@@ -367,6 +367,9 @@ typedef struct {
     float p_rr;
 } crt_task;
 int crt_task_load(const char* config_json_path, crt_task* out);
+/* Entry `index` (< n_objs) of the file's OBJ_paths: the two strings, NUL-terminated, into buffers of `cap` bytes each
+ * (CRT_ERR_INVALID_ARG if one does not fit or the index is out of range).  For configurations of more than eight OBJ files. */
+int crt_task_obj(const char* config_json_path, uint32_t index, char* obj_path, char* mtl_dir, uint32_t cap);
 
 /* What the reference's texture decoder returns for a map_Kd file -- stbi_load(path, &x, &y, &comp, 0) of Loader.h:58: 8-bit
  * samples, row 0 = top, the file's own channel count.  Decodes every format that decoder reads -- PNG (plain and Adam7), JPEG

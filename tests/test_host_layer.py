@@ -73,6 +73,28 @@ def test_task_parses_reference_config_schema(tmp_path):
     assert e.value.status == -5  # CRT_ERR_IO
 
 
+def test_task_with_more_than_eight_obj_files(tmp_path):
+    """src/main.cu:74-78 loops over any number of OBJ_paths entries; the crt_task POD has eight slots, crt_task_obj returns the rest, and
+    the scene built from eleven files (the stand-in room split into its shapes' worth of copies of one small OBJ) loads them all."""
+    import json
+    src = os.path.join(util.ROOT, "scenes", "veach-mis")
+    cfg = json.load(open(os.path.join(src, "config.json")))
+    cfg["OBJ_paths"] = [{"OBJ_path": os.path.join(src, "veach-mis.obj"), "MTL_dir": src + "/"} for _ in range(11)]
+    cfg["OBJ_paths"][9]["MTL_dir"] = src + "//"       # a marker to see that entry 9 is entry 9
+    p = tmp_path / "eleven.json"
+    p.write_text(json.dumps(cfg))
+    t = crt.Task(str(p))
+    assert len(t.OBJ_paths) == 11 and t.OBJ_paths[9][1].endswith("//") and t.OBJ_paths[10][0].endswith("veach-mis.obj")
+    one = crt.Scene.from_task(util.task("veach-mis"))
+    s = crt.Scene.from_task(t)
+    assert len(s.objects()) == 11 * len(one.objects()) and len(s.triangles()) == 11 * len(one.triangles())
+    lib = capi.lib()
+    o, m = C.create_string_buffer(8), C.create_string_buffer(8)
+    assert lib.crt_task_obj(os.fsencode(str(p)), 0, o, m, 8) == -1       # buffer too small
+    o, m = C.create_string_buffer(4096), C.create_string_buffer(4096)
+    assert lib.crt_task_obj(os.fsencode(str(p)), 11, o, m, 4096) == -1   # index out of range
+
+
 def test_loader_error_behaviour(tmp_path):
     s = crt.Scene(8, 8)
     with pytest.raises(crt.CrtError) as e:
