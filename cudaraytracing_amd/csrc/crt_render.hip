@@ -73,7 +73,8 @@ struct crt_scene {
 static bool use_ref16(const crt_scene* sc, int mode, bool dec = false)
 {
     if (mode == 1 || !(dec ? sc->ref16_inner_ok : sc->ref16_ok)) return false;
-    // CRT_REF16=0: the coupled form in its 32-bit layout whatever the scene; CRT_REF32=1: 32-bit stack entries in either form (tests, A/B)
+    // CRT_REF16=0 ("the leaf refs do not fit 16 bits"): 32-bit entries for the coupled form -- the decoupled form, which that setting
+    // selects where it can (use_dec), keeps its 16-bit entries; CRT_REF32=1: 32-bit stack entries in either form (tests, A/B)
     const char* e = std::getenv("CRT_REF16");
     const char* f = std::getenv("CRT_REF32");
     if (f && f[0] == '1') return false;

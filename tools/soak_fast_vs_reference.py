@@ -18,6 +18,7 @@ ap.add_argument("--seeds", type=int, nargs="+", default=[0])
 ap.add_argument("--out", default=None)
 ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
 ap.add_argument("--only", type=int, nargs="*", default=None, help="ranks to render (default: all)")
+ap.add_argument("--forms", default="default", help="comma list of pool forms the tested mode is rendered with: default, coupled (CRT_DEC=0), decoupled (CRT_DEC=1)")
 a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, a.width, a.height)
@@ -32,7 +33,14 @@ for seed in a.seeds:
     for rank in (a.only if a.only else range(a.ranks)):
         slots = crt.shard_slots(a.width, a.height, rank, a.ranks)
         res = {}
-        for name, trav in (("fast", crt.TRAVERSAL_EXACT if a.mode == "exact" else crt.TRAVERSAL_FAST), ("ref", crt.TRAVERSAL_REFERENCE)):
+        forms = [f for f in a.forms.split(",") if f]
+        runs = [("fast" if f == forms[0] else "fast_" + f, crt.TRAVERSAL_EXACT if a.mode == "exact" else crt.TRAVERSAL_FAST, f) for f in forms]
+        for name, trav, form in runs + [("ref", crt.TRAVERSAL_REFERENCE, "default")]:
+            os.environ.pop("CRT_DEC", None)
+            if form == "coupled":
+                os.environ["CRT_DEC"] = "0"
+            elif form == "decoupled":
+                os.environ["CRT_DEC"] = "1"
             r.traversal = trav
             buf = np.zeros((slots, 3), dtype=np.uint8)
             mean = np.zeros((slots, 3), dtype=np.float32)
@@ -41,11 +49,12 @@ for seed in a.seeds:
             t0 = time.perf_counter()
             capi.check(capi.lib().crt_render(r._h, C.byref(cam), C.byref(prm), capi.ptr(buf), capi.ptr(mean), C.byref(st)), "crt_render")
             res[name] = (mean, st.rays, time.perf_counter() - t0)
-        bad = int(np.count_nonzero(np.any(res["fast"][0].view(np.uint32) != res["ref"][0].view(np.uint32), axis=1)))
+        bad = sum(int(np.count_nonzero(np.any(res[n][0].view(np.uint32) != res["ref"][0].view(np.uint32), axis=1))) for n in res if n != "ref")
         total_rays += res["fast"][1]
         total_bad += bad
         line = {"mode": a.mode, "scene": a.scene, "size": [a.width, a.height, a.spp], "seed": seed, "rank": rank, "of": a.ranks, "rays": int(res["fast"][1]),
-                "rays_equal": bool(res["fast"][1] == res["ref"][1]), "slots_differ": bad, "fast_s": round(res["fast"][2], 2), "ref_s": round(res["ref"][2], 2)}
+                "rays_equal": all(res[n][1] == res["ref"][1] for n in res), "slots_differ": bad, "forms": forms,
+                "form_s": {n: round(res[n][2], 2) for n in res}, "fast_s": round(res["fast"][2], 2), "ref_s": round(res["ref"][2], 2)}
         print(json.dumps(line), flush=True)
         if a.out:
             with open(a.out, "a") as f:
