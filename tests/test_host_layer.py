@@ -207,6 +207,28 @@ def test_bench_started_plainly_with_several_gpus_starts_its_ranks(tmp_path):
     assert "must be launched with" not in r.stderr
 
 
+def test_bench_workload_aliases_are_the_baseline_configurations(monkeypatch):
+    """bench.py --workload c2..c5 = BASELINE.json's configs[1..4] (scene, size, spp); single fields can be overridden, and only an exact
+    BASELINE configuration carries its id into the line (the id selects hash-stamped counters and the share model)."""
+    import json
+    import bench
+    base = json.load(open(os.path.join(util.ROOT, "BASELINE.json")))["configs"]
+    for wl, cfg in zip(("c2", "c3", "c4", "c5"), base[1:]):
+        scene, w, h, spp = bench.WORKLOADS[wl]
+        assert cfg.startswith(scene + ".obj %dx%d spp=%d" % (w, h, spp)), (wl, cfg)
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", wl])
+        a = bench.parse_args()
+        assert (a.scene, a.width, a.height, a.spp, a.workload_id) == (scene, w, h, spp, wl)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.scene, a.width, a.height, a.spp, a.workload_id) == ("cornell-box", 800, 600, 512, "c2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "c4", "--spp", "8"])
+    a = bench.parse_args()
+    assert (a.scene, a.width, a.height, a.spp, a.workload_id) == ("cornell-box", 3840, 2160, 8, None)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--scene", "veach-mis", "--spp", "1024"])
+    assert bench.parse_args().workload_id == "c3"
+
+
 def test_header_constants_match_the_python_mirror():
     """include/crt.h is the contract: the enum values the Python mirror passes must be the header's, and the default traversal mode
     (a zeroed crt_params) must be the provably exact one."""
