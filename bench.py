@@ -559,10 +559,12 @@ def main_rank(args):
                 c3["bounds"] = bounds_from_pmc(p3, float(np.mean(k3)) * 1e-3, load_census("c3"))
             r3.free()
 
-        # ---- the mesh-size cliff: the stand-in's leaf records fit the 16-bit stack entries of the coupled pool; a mesh of the
-        #      reference's real size does not and renders with the decoupled-leaves pool.  Timed here: the stand-in under that layout
-        #      (CRT_REF16=0: "the leaf records do not fit"), under the coupled pool's 32-bit layout (what such a mesh got in rounds 1-3), and a
-        #      102 412-triangle variant of the scene (scenes/gen_cornell_box.py --detail 6,5), same camera, same spp ----
+        # ---- mesh size: rounds 1-3 rendered the stand-in with 16-bit stack entries that hold leaf refs too (the coupled
+        #      pool: <= 32 768 leaf records) and anything larger 9 % slower.  The default is now the decoupled-leaves pool, whose layout
+        #      does not depend on the number of leaves (four-wide nodes < 32 768: about 160 000 triangles).  Timed here: the stand-in
+        #      under the default, under the coupled pool with 16-bit entries (the round-3 default) and with 32-bit entries (what a larger
+        #      mesh got in rounds 1-3), and a 102 412-triangle variant of the scene (scenes/gen_cornell_box.py --detail 6,5), same
+        #      camera, same spp ----
         large = None
         if single and c2 and not multi and not args.no_large_scene:
             def timed_frames(rr, n=3):
@@ -590,7 +592,7 @@ def main_rank(args):
                             os.environ[k] = v
             render.set_spp(args.spp)
             render.traversal = trav
-            ms_large_layout, k_large_layout, _ = with_env({"CRT_REF16": "0"}, lambda: timed_frames(render))
+            ms_coupled16, k_coupled16, _ = with_env({"CRT_DEC": "0"}, lambda: timed_frames(render))
             ms_coupled32, k_coupled32, _ = with_env({"CRT_DEC": "0", "CRT_REF16": "0"}, lambda: timed_frames(render))
             ms_default, k_default, _ = with_env({}, lambda: timed_frames(render))
             import tempfile
@@ -608,12 +610,12 @@ def main_rank(args):
                 ms_l, k_l, st_l = with_env({}, lambda: timed_frames(rl))
                 ms_l32, k_l32, _ = with_env({"CRT_DEC": "0"}, lambda: timed_frames(rl))
                 rl.free()
-            large = {"standin_default_layout_ms": round(ms_default, 3), "standin_large_mesh_layout_ms": round(ms_large_layout, 3),
-                     "standin_large_mesh_layout_over_default": round(ms_large_layout / ms_default, 4),
+            large = {"standin_default_layout_ms": round(ms_default, 3), "standin_coupled_16bit_layout_ms": round(ms_coupled16, 3),
                      "standin_coupled_32bit_layout_ms": round(ms_coupled32, 3),
-                     "layouts": "default: coupled pool, eight 16-bit stack levels in LDS (node and leaf refs < 32 768); large-mesh: decoupled leaves, "
-                                "six 16-bit levels of inner nodes (four-wide nodes < 32 768, any number of leaves: CRT_REF16=0 forces it on the stand-in); "
-                                "coupled 32-bit: four LDS levels (what a larger mesh rendered with in rounds 1-3)",
+                     "layouts": "default: decoupled leaves, six 16-bit stack levels of inner nodes in LDS + a leaf queue (four-wide nodes < 32 768, "
+                                "any number of leaves -- the stand-in and a mesh of the reference's size render with the same kernel); coupled 16-bit "
+                                "(CRT_DEC=0; the default of rounds 2-3): eight 16-bit levels, node and leaf refs < 32 768; coupled 32-bit "
+                                "(CRT_DEC=0 CRT_REF16=0): four LDS levels (what a larger mesh rendered with in rounds 1-3)",
                      "large_scene": {"workload": "cornell-box --detail 6,5: %d triangles, %d leaf records, %d four-wide nodes, %dx%d spp=%d"
                                                  % (n_tri_l, ai_l["n_leaves"], ai_l["n_nodes4"], args.width, args.height, args.spp),
                                      "layout_caps": ai_l["layout_caps"], "ms_per_frame": round(ms_l, 3), "kernel_ms": round(k_l, 3),

@@ -627,21 +627,23 @@ __device__ __forceinline__ void stack_push(LDS& S, const MParams3& M3, const uin
 // near and far planes (picked by the sign of the direction, the reference's own swap), the nearest hit child next, the others pushed
 // farthest first.  Which children are visited, and in which order, does not change the result (crt_trace.h); the boxes and the test
 // are the reference's (hit_AABB, exact for finite operands), so a leaf is entered iff its own box passes -- as in the 2-wide tree.
-template <bool STATS, bool SORT = true, class LDS = Pool3Lds>
-__device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+template <bool STATS, bool SORT = true, class LDS = Pool3Lds, bool DIR = false>
+__device__ __forceinline__ bool inner4_step(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv_or_d,
                                             const float bound, int& ref, int& sp, TravCounters& tc, uint32_t& max_sp
                                             )
 {
     const char* nb = (const char*)sc.nodes4; // 32-bit byte offsets: scalar base + vector offset addressing
     const uint32_t noff = (uint32_t)ref * 128u;
-    const uint32_t ox = noff + ((__float_as_uint(inv.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv.y) >> 27) & 16u),
-                   oz = noff + ((__float_as_uint(inv.z) >> 27) & 16u); // + 16: the ray runs towards -axis, its near plane is hi
+    // (DIR: the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
+    const uint32_t ox = noff + ((__float_as_uint(inv_or_d.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv_or_d.y) >> 27) & 16u),
+                   oz = noff + ((__float_as_uint(inv_or_d.z) >> 27) & 16u); // + 16: the ray runs towards -axis, its near plane is hi
     const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
     const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 96);
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
     if (STATS) tc.inner++;
+    const F3 inv = DIR ? inv3_exact(inv_or_d) : inv_or_d;
     float t0, t1, t2, t3; // entry distances; +inf = missed or beyond the pruning bound (sorts last)
     slab_quad_pruned<SORT>(a0, a1, a2, b0, b1, b2, o, inv, bound, t0, t1, t2, t3); // (SORT == pruning mode: CRT_SORT4)
     // (all four entry distances exist before the exchanges and pushes begin: left alone the compiler starts pushing the first pair's
@@ -938,7 +940,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const float4 qa = S.A[id], qbd = S.B[id];
                 const uint32_t qd = S.D[id];
                 int ref = S.node[id];
-                const F3 o = f3(qa.x, qa.y, qa.z), inv = inv3_exact(f3(qbd.x, qbd.y, qbd.z));
+                // (EXACT, no ray of the batch on the reference-arithmetic path: the step takes the direction itself and forms 1 / d after its
+                // loads are on their way)
+                constexpr bool DIR_ = MODE == 2 && !MAY_EXACT;
+                const F3 o = f3(qa.x, qa.y, qa.z), inv = DIR_ ? f3(qbd.x, qbd.y, qbd.z) : inv3_exact(f3(qbd.x, qbd.y, qbd.z));
                 int sp = (int)(qd & 0xffu);
                 // pruning bound: fixed by the light distance for shadow rays, shrinking with the best hit otherwise
                 // (MODE 2 = CRT_TRAVERSAL_EXACT: the same traversal without this bound; +inf = no bound -- a box entered at +inf is still
@@ -949,7 +954,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const float4 qb = S.B[id];
                     done = inner2_step<1, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), bound, ref, sp, tc, max_sp);
                 } else if (!MAY_EXACT) {
-                    done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp);
+                    done = inner4_step<STATS, CRT_SORT4(MODE), LDS3, DIR_>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp);
                 } else {
                     const bool ex = (qd & RF_EXACT) != 0;
                     if (!ex) done = inner4_step<STATS, CRT_SORT4(MODE)>(sc, S, M3, id, g, o, inv, bound, ref, sp, tc, max_sp);
@@ -1194,26 +1199,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         };
 #undef PUSH_ONE
         const bool plain = MODE == 1 || n_exact == 0;
+        // The two traversal steps ALTERNATE without going back to the scheduler while the other side holds a batch and no logic ring holds
+        // a full one: the scheduler's comparison of the five rings (36 scalar instructions -- a third of them copies of the loop-carried
+        // ring cursors -- and the dispatch on its result) stands between every two steps of the wave, and a wave issues one instruction
+        // at a time whatever its kind.  Coupled form: C2 92.6 -> 91.1 ms, veach-mis spp 256 88.0 -> 84.8 with CHAIN_MIN 44
+        // (56 / 48 / 40 / 32 / 20: 93.0 / 91.3 / 91.2 / 91.7 / 93.2 and 85.9 / 84.9 / 84.9 / 86.2 / 90.2); decoupled form: 92.2 -> 87.7 and
+        // 89.5 -> 84.8 (32 / 52: the same).  Not taken: staying on the SAME ring while it holds another full batch (92.9 / 86.7); one chained
+        // step only, each arm compiled twice (92.1 / 86.0); the same preference expressed in the scheduler's keys (no gain); a short-cut in
+        // front of the scheduler (93.6 / 88.7).
+        constexpr int CHAIN_MIN = 44;
+        auto logic_waits = [&]() __attribute__((always_inline)) {
+            if constexpr (STATS) return max(max(qn[PH3_LA], qn[PH3_LB]), qn[PH3_LC]) >= 64; // (the counting kernels' cursors may live in vector registers)
+            else return smax(smax(qn[PH3_LA], qn[PH3_LB]), qn[PH3_LC]) >= 64;
+        };
         if constexpr (DEC) {
-            if (act == PH3_INNER) {
-                if (plain)
-                    inner_arm_dec(std::false_type{});
-                else
-                    inner_arm_dec(std::true_type{});
+            // (the leaf queue goes first while it holds LEAFQ_FIRST entries, as in the scheduler)
+            if (plain) {
+                bool do_inner = act == PH3_INNER;
+                for (;;) {
+                    if (do_inner) {
+                        inner_arm_dec(std::false_type{});
+                        if ((int)(lq_t - lq_h) < LEAFQ_FIRST || logic_waits()) break;
+                    }
+                    leaf_arm_dec();
+                    if (logic_waits()) break;
+                    do_inner = (int)(lq_t - lq_h) < LEAFQ_FIRST;
+                    if (do_inner && qn[PH3_INNER] < CHAIN_MIN) break;
+                }
+            } else if (act == PH3_INNER) {
+                inner_arm_dec(std::true_type{});
             } else {
                 leaf_arm_dec();
             }
         } else {
-        if (act == PH3_INNER) {
-            if (plain)
-                inner_arm(std::false_type{});
-            else
-                inner_arm(std::true_type{});
-        } else {
-            if (plain)
+        if (plain) {
+            bool do_inner = act == PH3_INNER;
+            for (;;) {
+                if (do_inner) {
+                    inner_arm(std::false_type{});
+                    if (qn[PH3_LEAF] < CHAIN_MIN || logic_waits()) break;
+                }
                 leaf_arm(std::false_type{});
-            else
-                leaf_arm(std::true_type{});
+                if (qn[PH3_INNER] < CHAIN_MIN || logic_waits()) break;
+                do_inner = true;
+            }
+        } else if (act == PH3_INNER) {
+            inner_arm(std::true_type{});
+        } else {
+            leaf_arm(std::true_type{});
         }
         }
       }

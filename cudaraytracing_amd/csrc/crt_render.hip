@@ -73,8 +73,8 @@ struct crt_scene {
 static bool use_ref16(const crt_scene* sc, int mode, bool dec = false)
 {
     if (mode == 1 || !(dec ? sc->ref16_inner_ok : sc->ref16_ok)) return false;
-    // CRT_REF16=0 ("the leaf refs do not fit 16 bits"): 32-bit entries for the coupled form -- the decoupled form, which that setting
-    // selects where it can (use_dec), keeps its 16-bit entries; CRT_REF32=1: 32-bit stack entries in either form (tests, A/B)
+    // CRT_REF16=0 ("the leaf refs do not fit 16 bits"): 32-bit entries for the coupled form -- the decoupled form keeps its 16-bit
+    // entries; CRT_REF32=1: 32-bit stack entries in either form (tests, A/B)
     const char* e = std::getenv("CRT_REF16");
     const char* f = std::getenv("CRT_REF32");
     if (f && f[0] == '1') return false;
@@ -269,19 +269,18 @@ uint32_t env_u32(const char* name, uint32_t dflt)
 
 // The instantiation of k_mega3 for a traversal mode (0 FAST, 1 REFERENCE, 2 EXACT), with or without counters, every sample traced
 // or not (FAST only), render or query form, 32- or 16-bit stack entries (never for REFERENCE)
-// The decoupled-leaves form (Pool4LdsT) of a launch: CRT_TRAVERSAL_EXACT on a scene whose leaf records fit a queue entry.  It is
-// the layout of the scenes whose leaf records no longer fit 16-bit stack entries while their four-wide nodes do (about 50 000 to
-// 160 000 triangles): its stack holds inner nodes only.  On the smaller scenes the coupled form is 1 - 3 % faster and
-// stays the default.  CRT_DEC=1 / 0 forces / forbids it (tests, A/B); CRT_REF16=0 ("the leaf records do not fit") selects it too.
+// The decoupled-leaves form (Pool4LdsT) of a launch: CRT_TRAVERSAL_EXACT on a scene whose four-wide nodes fit the 16-bit entries of
+// its stack (inner nodes only: up to about 160 000 triangles) and whose leaf records fit a queue entry.  Since the traversal steps
+// alternate without the scheduler (crt_mega3.hip, CHAIN_MIN) it is the faster form on every scene measured (stand-in cornell-box
+// - 4 %, veach-mis equal, the 102 412-triangle variant - 5 % against the coupled form with 32-bit entries), and the one whose
+// layout does not change with the number of leaves.  CRT_DEC=1 / 0 forces / forbids it (tests, A/B).
 static bool use_dec(const crt_scene* sc, int mode)
 {
     if (mode != 2 || !sc->dec_ok) return false;
     const char* e = std::getenv("CRT_DEC");
     if (e && e[0] == '0') return false;
     if (e && e[0] == '1') return true;
-    const char* r = std::getenv("CRT_REF16");
-    const bool fits16 = sc->ref16_ok && !(r && r[0] == '0');
-    return !fits16 && sc->ref16_inner_ok;
+    return sc->ref16_inner_ok;
 }
 // Which pipeline renders: 4 = k_mega3 (the product), 2 = the wavefront pipeline (k_logic + k_trace).  k_mega3 keeps the best
 // triangle's offset inside its leaf in 16 bits, addresses nodes and leaf records with 32-bit byte offsets and the traversal stack

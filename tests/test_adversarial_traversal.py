@@ -457,7 +457,8 @@ LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_render.hip: 
     "coupled-32": {"CRT_DEC": "0", "CRT_REF16": "0"},
     "decoupled-16": {"CRT_DEC": "1"},
     "decoupled-32": {"CRT_DEC": "1", "CRT_REF32": "1"},
-    "auto, leaf records beyond 16 bits": {"CRT_REF16": "0"},  # what a scene of 50 000 - 160 000 triangles gets: decoupled-16
+    "default": {},  # decoupled-16 for CRT_TRAVERSAL_EXACT on a scene of up to about 160 000 triangles, coupled-16 for the other modes
+    "default, leaf records beyond 16 bits": {"CRT_REF16": "0"},  # a scene of 50 000 - 160 000 triangles: coupled-32 for the other modes
 }
 
 

@@ -16,11 +16,12 @@ import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def decoupled(monkeypatch):
+@pytest.fixture(autouse=True, params=["1", "0"], ids=["decoupled", "coupled"])
+def form(monkeypatch, request):
+    """Every case in both forms: CRT_TRAVERSAL_EXACT takes the decoupled one by default, so the coupled one is forced here too."""
     for k in ("CRT_REF16", "CRT_REF32"):
         monkeypatch.delenv(k, raising=False)
-    monkeypatch.setenv("CRT_DEC", "1")
+    monkeypatch.setenv("CRT_DEC", request.param)
 
 
 @pytest.mark.parametrize("thresh", [1, 2, 4])

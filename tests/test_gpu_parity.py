@@ -155,7 +155,7 @@ def test_render_crops_match_oracle(renders, name, mode):
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
-def test_small_full_frame_matches_oracle_with_counters(renders, name):
+def test_small_full_frame_matches_oracle_with_counters(renders, name, monkeypatch):
     """Whole 96x72 frame incl. ragged 8x8 tiles, ray counters against the oracle's."""
     t = util.task(name)
     eye, iv, fov = util.camera(name)
@@ -179,10 +179,15 @@ def test_small_full_frame_matches_oracle_with_counters(renders, name):
             exact_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
         else:
             fast_visits = (r.stats["inner_pops"], r.stats["leaf_pops"])
-    # pruning only ever removes visits -- between two walks in the same order: with the leaves decoupled (CRT_DEC=1) an any-hit ray
-    # of EXACT meets its leaves in another order than FAST's and may stop earlier
+    # pruning only ever removes visits -- between two walks in the same order: with the leaves decoupled (EXACT's default form) an any-hit
+    # ray meets its leaves in another order than FAST's and may stop earlier, so the comparison is with EXACT in the coupled form
     if os.environ.get("CRT_DEC") != "1":
-        assert exact_visits[0] >= fast_visits[0] and exact_visits[1] >= fast_visits[1]
+        monkeypatch.setenv("CRT_DEC", "0")
+        r.traversal = crt.TRAVERSAL_EXACT
+        rgb3 = r.run_view(eye, iv, fov, stats=True, width=w, height=h)
+        assert np.array_equal(rgb3, orgb) and r.stats["rays"] == st["rays"]
+        assert r.stats["inner_pops"] >= fast_visits[0] and r.stats["leaf_pops"] >= fast_visits[1]
+        monkeypatch.delenv("CRT_DEC")
 
 
 @pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])

@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import report  # noqa: E402
 
-SYM = "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
+SYM = "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1EEEvNS_8MParams3E"
 
 
 def main():

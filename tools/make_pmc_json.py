@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 from cudaraytracing_amd import build as B
 
 # the default render path: EXACT traversal (FAST as a fallback for older profiles), no counting, zero-contribution samples answered without traversal, not the query form
-DEFAULT_KERNEL = ("k_mega3<2, false, false, false, true, false, false>", "k_mega3<2, false, false, false, true, false, true>",   # (MODE, STATS, ALL, QUERY, R16, RING, DEC)
+DEFAULT_KERNEL = ("k_mega3<2, false, false, false, true, false, true>", "k_mega3<2, false, false, false, true, false, false>",   # (MODE, STATS, ALL, QUERY, R16, RING, DEC)
                   "k_mega3<2, false, false, false, false, false, true>", "k_mega3<2, false, false, false, false, false, false>",
                   "k_mega3<2, false, false, false, true, false>", "k_mega3<2, false, false, false, false, false>",   # (MODE, STATS, ALL, QUERY, R16, RING)
                   "k_mega3<2, false, false, false, true>", "k_mega3<2, false, false, false, false>",
