@@ -156,7 +156,7 @@ struct Pool4LdsT {
     unsigned long long best[P];  // the ray's answer so far: bits(distance) << 32 | ~triangle; FLT_MAX << 32 | 0 = nothing
     stk_t stk[LV][P];            // traversal stack (inner nodes only); deeper levels spill to global memory
     uint32_t D[P];               // stack depth (bits 0-7) | entries in flight (RD_PEND_MASK) | RF_* flags, RD_FIN
-    uint32_t leafq[LEAFQ_CAP];
+    uint32_t leafq[LEAFQ_CAP + 1]; // (+ a spare dword: where the lanes without an entry write in the branch-free append)
     uint8_t ring[(RING_ ? 5 : 4)][QCAP]; // INNER, LA, LB, LC (, WAIT)
     uint32_t waitq;
     __device__ __forceinline__ uint8_t* rq(const int p) { return ring[p == PH3_INNER ? 0 : p - 1]; }

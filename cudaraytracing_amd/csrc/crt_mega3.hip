@@ -703,24 +703,36 @@ __device__ __forceinline__ void leafq_push(LDS& S, const uint32_t id, const bool
         added += (uint32_t)__popcll(m);
     }
 }
+// The same append without a branch, for the four children of a 4-wide step (m is empty for one child in five, and a taken branch costs
+// more than the eight instructions it skips): a lane without an entry writes to the spare dword behind the queue, and the ray's count
+// of entries in flight is the caller's (one addition for the four children).
+template <class LDS>
+__device__ __forceinline__ void leafq_push_all(LDS& S, const bool hit, const unsigned long long m, const uint32_t entry, uint32_t& tail)
+{
+    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
+    S.leafq[hit ? (slot & (uint32_t)(LEAFQ_CAP - 1)) : (uint32_t)LEAFQ_CAP] = entry;
+    tail += (uint32_t)__popcll(m);
+}
 template <bool STATS, class LDS>
-__device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 inv,
+__device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 dir,
                                                 int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
-                                                const bool enable)
+                                                uint32_t& n_leaf, const bool enable)
 {
     // (every lane of the batch runs the step, so that the appends -- ballots, the running count `added` -- stay wave-uniform; a lane
     // without `enable`, an any-hit ray that has its answer or a ray of the reference-arithmetic path, steps at the EMPTY node the host
     // puts behind the tree -- four inverted boxes: nothing is hit, appended or pushed)
     const char* nb = (const char*)sc.nodes4;
     const uint32_t noff = enable ? (uint32_t)ref * 128u : sc.empty4_off;
-    const uint32_t ox = noff + ((__float_as_uint(inv.x) >> 27) & 16u), oy = noff + ((__float_as_uint(inv.y) >> 27) & 16u),
-                   oz = noff + ((__float_as_uint(inv.z) >> 27) & 16u);
+    // (the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
+    const uint32_t ox = noff + ((__float_as_uint(dir.x) >> 27) & 16u), oy = noff + ((__float_as_uint(dir.y) >> 27) & 16u),
+                   oz = noff + ((__float_as_uint(dir.z) >> 27) & 16u);
     const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
     const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 112);
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
     if (STATS && enable) tc.inner++;
+    const F3 inv = inv3_exact(dir);
     float t0, t1, t2, t3;
     slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
@@ -733,10 +745,13 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     const bool n0 = r0 < 0, n1 = r1 < 0, n2 = r2 < 0, n3 = r3 < 0;
     const bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
 #define CRT_LEAF_MASK(h_, n_) (__builtin_amdgcn_ballot_w64(h_) & __builtin_amdgcn_ballot_w64(n_))
-    leafq_push(S, id, l0, CRT_LEAF_MASK(h0, n0), ((uint32_t)r0 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l1, CRT_LEAF_MASK(h1, n1), ((uint32_t)r1 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l2, CRT_LEAF_MASK(h2, n2), ((uint32_t)r2 & 0x7fffff00u) | id, lq_t, added);
-    leafq_push(S, id, l3, CRT_LEAF_MASK(h3, n3), ((uint32_t)r3 & 0x7fffff00u) | id, lq_t, added);
+    uint32_t tail = lq_t + added;
+    leafq_push_all(S, l0, CRT_LEAF_MASK(h0, n0), ((uint32_t)r0 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l1, CRT_LEAF_MASK(h1, n1), ((uint32_t)r1 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l2, CRT_LEAF_MASK(h2, n2), ((uint32_t)r2 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l3, CRT_LEAF_MASK(h3, n3), ((uint32_t)r3 & 0x7fffff00u) | id, tail);
+    added = tail - lq_t;
+    n_leaf = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
 #undef CRT_LEAF_MASK
     any_leaf = l0 | l1 | l2 | l3;
     t0 = n0 ? inf : t0; t1 = n1 ? inf : t1; t2 = n2 ? inf : t2; t3 = n3 ? inf : t3;
@@ -760,8 +775,15 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     }
     sp = sp_new;
     if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-    if (c0) { ref = r0; return false; }
-    return stack_pop_ahead(S, M, id, g, sp, ref, top, LV);
+    // the nearest inner child next; without one (nothing was pushed either: the top is the one read above) the stack's top, or the end
+    const bool pop = !c0 & (sp > 0);
+    const bool over = !c0 & (sp == 0);
+    ref = c0 ? r0 : top;
+    sp -= pop ? 1 : 0;
+    if (__builtin_amdgcn_ballot_w64(pop & (sp >= LV))) {
+        if (pop & (sp >= LV)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
+    }
+    return over;
 }
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
@@ -1077,19 +1099,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const uint32_t qd = S.D[id];
                 const uint32_t blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 int ref = __float_as_int(qb.w);
-                const F3 o = f3(qa.x, qa.y, qa.z), inv = inv3_exact(f3(qb.x, qb.y, qb.z));
+                const F3 o = f3(qa.x, qa.y, qa.z), dir = f3(qb.x, qb.y, qb.z);
                 int sp = (int)(qd & 0xffu);
                 // an any-hit ray that has its answer looks no further (entries of it still in the queue are tested and change nothing)
                 bool done = (qd & RF_ANYHIT) != 0 && blo != 0u;
                 const bool go = !done;
                 const bool ex = MAY_EXACT && (qd & RF_EXACT) != 0;
-                uint32_t added = 0;
+                uint32_t added = 0, n_leaf = 0; // entries of the batch so far (wave-uniform); entries of this ray from its 4-wide step
                 bool any_leaf = false;
                 {
                     // (a lane that does not take the step -- see inner4_step_dec -- keeps its node, depth and `done`)
                     const bool en = go && !ex;
                     int ref4 = ref, sp4 = sp;
-                    const bool done4 = inner4_step_dec<STATS>(sc, S, M3, id, g, o, inv, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, en);
+                    const bool done4 = inner4_step_dec<STATS>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en);
                     if (en) { ref = ref4; sp = sp4; done = done4; }
                 }
                 if (MAY_EXACT) {
@@ -1101,7 +1123,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                                 any_leaf = true;
                                 done = stack_pop(S, M3, id, g, sp, ref, lds_levels<LDS3>(true));
                             } else {
-                                done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv, f3(qb.x, qb.y, qb.z), pinf(), ref, sp, tc, max_sp);
+                                done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv3_exact(dir), dir, pinf(), ref, sp, tc, max_sp);
                             }
                         }
                     }
@@ -1110,7 +1132,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 // (leafq_push above: those additions are in LDS before this one, same wave, in order)
                 if (STATS) { for (int k = 0; k < 6; k++) dg_sp[k] += sp > k + 1 ? 1u : 0u; }
                 S.B[id].w = __int_as_float(ref);
-                __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (done ? RD_FIN : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (done ? RD_FIN : 0u) + (n_leaf << RD_PEND_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool comp = done & !any_leaf & ((qd & RD_PEND_MASK) == 0u);
                 if (STATS && comp && blo != 0u) tc.hits++;
                 if (__builtin_amdgcn_ballot_w64(comp)) nph = comp ? route_complete<QUERY>(qd, blo != 0u) : nph;
