@@ -1,6 +1,7 @@
 #!/bin/bash
 # Collects the judged profile artefacts on the GPU box into gpurun_out/profiles_<tag>/:
-#   stats/   rocprofv3 --kernel-trace --stats of the default bench.py command
+#   stats/   rocprofv3 --kernel-trace --stats of bench.py (--no-large-scene: the 102 412-triangle frames of the default command run the
+#            same instantiation of k_mega3 as the headline frames and would enter its average; --no-c3 likewise)
 #   c2_*/    PMC passes of one full-size C2 frame (cornell-box 800x600 spp 512), one --pmc group per run, FETCH_SIZE and
 #            WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes (never combined with trace domains)
 #   c3_*/    the same groups on one C3 frame (veach-mis 800x600 spp 1024)
@@ -12,7 +13,7 @@ cyc=${2:-2.0}
 out=gpurun_out/profiles_$tag
 export TMPDIR=/tmp
 mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-c3 > $out/bench_stats.log 2>&1 || echo "stats pass failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c3 --no-large-scene > $out/bench_stats.log 2>&1 || echo "stats pass failed"
 groups=(
 "FETCH_SIZE"
 "WRITE_SIZE"
