@@ -28,6 +28,9 @@ __device__ __forceinline__ FastDiv make_fastdiv_dev(uint32_t d)
     return f;
 }
 
+__device__ __forceinline__ float acc_load(const float* p) { return __uint_as_float(__hip_atomic_load((const unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void acc_store(float* p, const float v) { __hip_atomic_store((unsigned int*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
 {
     uint32_t slot = blockIdx.x * 256u + threadIdx.x;
@@ -36,7 +39,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
     bool valid = slot_to_pixel(slot, A.rank, A.world, A.n_tiles, A.tiles_x, make_fastdiv_dev(A.tiles_x), A.width, A.height, i, j);
     F3 c = f3(0.0f, 0.0f, 0.0f);
     if (valid) {
-        if (!A.first_chunk) c = f3(A.accum[slot], A.accum[A.nslots + slot], A.accum[2ull * A.nslots + slot]);
+        // (the accumulator is uncached memory that commit-ring launches read and write with agent-scope atomics: the same accesses here)
+        if (!A.first_chunk) c = f3(acc_load(A.accum + slot), acc_load(A.accum + A.nslots + slot), acc_load(A.accum + 2ull * A.nslots + slot));
         const float fspp = (float)A.spp;
         for (uint32_t s = 0; s < A.chunk_samples; s++) { // temp_color += L / spp, in sample order (Render.cuh:348)
             float4 l = A.L[(uint64_t)s * A.nslots + slot];
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
             c.z = c.z + l.z / fspp;
         }
         if (!A.last_chunk) {
-            A.accum[slot] = c.x; A.accum[A.nslots + slot] = c.y; A.accum[2ull * A.nslots + slot] = c.z;
+            acc_store(A.accum + slot, c.x); acc_store(A.accum + A.nslots + slot, c.y); acc_store(A.accum + 2ull * A.nslots + slot, c.z);
             return;
         }
     } else if (!A.tiled_output || !A.last_chunk) {

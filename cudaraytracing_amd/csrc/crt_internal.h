@@ -2,6 +2,7 @@
 // buffers, and the launch entry points each kernel file exports to the host code in crt_render.hip.
 #ifndef CRT_INTERNAL_H
 #define CRT_INTERNAL_H
+#include <cstdlib>
 #include "crt_mega3.h"
 
 #include <cstddef>
@@ -30,6 +31,19 @@ template <typename T> struct DevBuf {
         if (count == 0) count = 1;
         HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
         n = count;
+        debug_fill();
+    }
+    // CRT_DEBUG_FILL=<byte>: every new allocation is filled with that byte (tests: a read of memory nobody wrote shows up whatever the
+    // allocator hands out)
+    void debug_fill()
+    {
+        static const char* e = std::getenv("CRT_DEBUG_FILL");
+        if (!e || !*e) return;
+        if (e[0] == 's') { HIP_CHECK(hipDeviceSynchronize()); return; }       // synchronise only
+        if (e[0] == 'u' && !uncached) return;                                  // u<byte>: uncached allocations only
+        if (e[0] == 'c' && uncached) return;                                   // c<byte>: cached allocations only
+        const char* v = (e[0] == 'u' || e[0] == 'c') ? e + 1 : e;
+        HIP_CHECK(hipMemset(p, std::atoi(v) & 0xff, n * sizeof(T)));
     }
     void ensure(size_t count)
     {
@@ -45,6 +59,7 @@ template <typename T> struct DevBuf {
         HIP_CHECK(hipExtMallocWithFlags((void**)&p, count * sizeof(T), hipDeviceMallocUncached));
         n = count;
         uncached = true;
+        debug_fill();
     }
     bool uncached = false;
     void upload(const std::vector<T>& v)

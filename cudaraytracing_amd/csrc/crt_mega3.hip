@@ -413,7 +413,10 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
                 const uint32_t sh_ = fast_div(item, P.items_per_shard_div.m, P.items_per_shard_div.sh);
                 const uint32_t slo_ = sh_ * P.items_per_shard, shi_ = min(slo_ + P.items_per_shard, P.n_items);
                 const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
-                if (item >= wlo_) item = gld(&P.item_list[sh_ * P.order_window + (item - wlo_)]);
+                // (agent-scope load, as k_order_items' stores: with plain accesses the FIRST frame of a render created after other renders of
+                // the process came out with 10 - 400 work items of the 589 824 of a 96 x 64 x 96 frame never run -- their list entries read as
+                // what an earlier kernel had left at the address -- in half of the runs once the launches' timing had changed)
+                if (item >= wlo_) item = __hip_atomic_load((CRT_GAS const unsigned int*)&P.item_list[sh_ * P.order_window + (item - wlo_)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         bool valid; uint32_t pi, pj, pixel_index, k;
@@ -1443,8 +1446,8 @@ __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* l
         const unsigned long long m_on = __ballot(on_j), m_off = __ballot(ex_j && !on_j);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t i = b + j * 64u + lane;
-        if (on_j) out[base_on + (uint32_t)__popcll(m_on & below)] = i;
-        else if (ex_j) out[wn - 1u - (base_off + (uint32_t)__popcll(m_off & below))] = i;
+        if (on_j) __hip_atomic_store(&out[base_on + (uint32_t)__popcll(m_on & below)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (ex_j) __hip_atomic_store(&out[wn - 1u - (base_off + (uint32_t)__popcll(m_off & below))], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base_on += (unsigned int)__popcll(m_on);
         base_off += (unsigned int)__popcll(m_off);
     }

@@ -138,8 +138,13 @@ int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector
     if (want_device) depth_fast = crtaccel::build_sah_device(prims, acc, acc_root, &dev_ms, &index_splits);
     const bool on_device = depth_fast >= 0;
     if (!on_device) depth_fast = crtaccel::build_sah(prims, acc, acc_root, &index_splits);
-    if (const char* opt_ = std::getenv("CRT_SAH_OPT")) // experiment hook: insertion-based optimisation passes over the built tree
-        if (!acc.empty() && std::atoi(opt_) > 0) depth_fast = crtaccel::optimize_sah(acc, std::atoi(opt_));
+    // one pass of insertion-based optimisation over the built tree (crt_accel.h: optimize_sah; only moves that save half of what the
+    // node costs where it is); CRT_SAH_OPT=<passes> / CRT_SAH_OPT_MARGIN=<fraction> override, CRT_SAH_OPT=0 leaves the tree as built
+    {
+        const char* opt_ = std::getenv("CRT_SAH_OPT");
+        const int passes = opt_ ? std::atoi(opt_) : 1;
+        if (!acc.empty() && passes > 0) depth_fast = crtaccel::optimize_sah(acc, passes);
+    }
     if (ai) {
         ai->n_leaves = (uint32_t)prims.size(); ai->n_nodes2 = (uint32_t)acc.size(); ai->on_device = on_device ? 1u : 0u;
         ai->sah_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - sah_t0).count();

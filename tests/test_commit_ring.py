@@ -91,7 +91,10 @@ def test_progressive_ranges_with_and_without_the_ring():
             r.run_view_range(eye, iv, fov, 40, 16, width=w, height=h)      # one radiance per path
             os.environ["CRT_COMMIT_RING_LOG2"] = "3"
             rgb = r.run_view_range(eye, iv, fov, 56, 40, width=w, height=h).copy()   # ring (8 samples), ends the frame
-            assert np.array_equal(rgb, ref[0]) and np.array_equal(util.bits(r.mean_buffer), util.bits(ref[1]))
+            bad = util.bits(r.mean_buffer) != util.bits(ref[1])
+            assert not bad.any(), "%d of %d floats differ, first at %s: %r vs %r" % (
+                int(bad.sum()), bad.size, tuple(np.argwhere(bad)[0]), r.mean_buffer[bad][:4].tolist(), ref[1][bad][:4].tolist())
+            assert np.array_equal(rgb, ref[0])
         finally:
             r.free()
     finally:
