@@ -128,7 +128,7 @@ static_assert(sizeof(Pool3Lds) * 4 * CRT_WAVES <= 160 * 1024, "the pool does not
 // leaves the inner ring once instead of once per leaf, and the stack holds inner nodes only -- six 16-bit levels cover scenes of
 // 32 768 four-wide nodes whatever the number of leaves (24-bit leaf refs travel in the queue entries).
 #ifndef LEAFQ_CAP
-#define LEAFQ_CAP 256 /* entries of the leaf queue, a power of two; an inner batch is cut to (free entries) / 4 rays */
+#define LEAFQ_CAP 256 /* entries of the leaf queue, a power of two; the inner step counts a visit's entries before it writes any (crt_mega3.hip: inner4_step_dec) */
 #endif
 static_assert((LEAFQ_CAP & (LEAFQ_CAP - 1)) == 0 && LEAFQ_CAP >= 128, "leaf queue: a power of two, room for half a batch of inner steps");
 #define RD_PEND_SHIFT 8

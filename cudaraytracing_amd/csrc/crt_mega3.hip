@@ -716,10 +716,13 @@ __device__ __forceinline__ void leafq_push_all(LDS& S, const bool hit, const uns
     S.leafq[hit ? (slot & (uint32_t)(LEAFQ_CAP - 1)) : (uint32_t)LEAFQ_CAP] = entry;
     tail += (uint32_t)__popcll(m);
 }
-template <bool STATS, class LDS>
+// CHECK: what happens when the queue cannot take the visit's entries (they are counted before anything is written).  0: cannot happen (the
+// caller cut the batch to a quarter of the free entries); 1: the lanes from `cap_left / 4` on are taken out of the visit (*voided: they keep
+// their state and are queued again); 2: the whole visit is dropped (*bailed).
+template <bool STATS, class LDS, int CHECK = 0>
 __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 dir,
                                                 int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
-                                                uint32_t& n_leaf, const bool enable)
+                                                uint32_t& n_leaf, const bool enable, const uint32_t cap_left = 0, bool* bailed = nullptr, bool* voided = nullptr)
 {
     // (every lane of the batch runs the step, so that the appends -- ballots, the running count `added` -- stay wave-uniform; a lane
     // without `enable`, an any-hit ray that has its answer or a ray of the reference-arithmetic path, steps at the EMPTY node the host
@@ -734,7 +737,6 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 112);
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
-    if (STATS && enable) tc.inner++;
     const F3 inv = inv3_exact(dir);
     float t0, t1, t2, t3;
     slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
@@ -746,13 +748,27 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     // compiler does not rewrite differently for the predicate and for the ballot)
     const bool h0 = __float_as_uint(t0) != 0x7f800000u, h1 = __float_as_uint(t1) != 0x7f800000u, h2 = __float_as_uint(t2) != 0x7f800000u, h3 = __float_as_uint(t3) != 0x7f800000u;
     const bool n0 = r0 < 0, n1 = r1 < 0, n2 = r2 < 0, n3 = r3 < 0;
-    const bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
 #define CRT_LEAF_MASK(h_, n_) (__builtin_amdgcn_ballot_w64(h_) & __builtin_amdgcn_ballot_w64(n_))
     uint32_t tail = lq_t + added;
-    leafq_push_all(S, l0, CRT_LEAF_MASK(h0, n0), ((uint32_t)r0 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l1, CRT_LEAF_MASK(h1, n1), ((uint32_t)r1 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l2, CRT_LEAF_MASK(h2, n2), ((uint32_t)r2 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l3, CRT_LEAF_MASK(h3, n3), ((uint32_t)r3 & 0x7fffff00u) | id, tail);
+    unsigned long long m0 = CRT_LEAF_MASK(h0, n0), m1 = CRT_LEAF_MASK(h1, n1), m2 = CRT_LEAF_MASK(h2, n2), m3 = CRT_LEAF_MASK(h3, n3);
+    bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
+    if (CHECK != 0) {
+        if ((uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)) > cap_left) {
+            if (CHECK == 2) { *bailed = true; return false; }
+            // the lanes a quarter of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
+            const bool keep = (uint32_t)(threadIdx.x & 63) < (cap_left >> 2);
+            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+            m0 &= km; m1 &= km; m2 &= km; m3 &= km;
+            l0 = l0 & keep; l1 = l1 & keep; l2 = l2 & keep; l3 = l3 & keep;
+            t0 = keep ? t0 : inf; t1 = keep ? t1 : inf; t2 = keep ? t2 : inf; t3 = keep ? t3 : inf;
+            *voided = !keep;
+        }
+    }
+    if (STATS && enable && !(CHECK == 1 && *voided)) tc.inner++;
+    leafq_push_all(S, l0, m0, ((uint32_t)r0 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l1, m1, ((uint32_t)r1 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l2, m2, ((uint32_t)r2 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, l3, m3, ((uint32_t)r3 & 0x7fffff00u) | id, tail);
     added = tail - lq_t;
     n_leaf = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
 #undef CRT_LEAF_MASK
@@ -934,12 +950,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         {
             // key = batch size * 8 + phase number (the phase numbers are the tie-break order)
             const int kC = min(qn[PH3_LC], 64) * 8 + PH3_LC, kA = min(qn[PH3_LA], 64) * 8 + PH3_LA, kB = min(qn[PH3_LB], 64) * 8 + PH3_LB;
-            // (DEC: the leaf queue counts entries, not rays; with 64 or more it is the fullest there can be and wins over the inner ring,
-            // so an inner batch always finds room for 4 entries per ray of at least 48 rays)
+            // (DEC: the leaf queue counts entries, not rays; with 64 or more it is the fullest there can be and wins over the inner ring)
 #ifndef LEAFQ_FIRST
-#define LEAFQ_FIRST 48 /* DEC: with this many entries the leaf queue goes before everything else -- at 64 an inner batch is cut to (256 - entries) / 4 = 48 .. 64
-                          rays (measured fill 55); from 48 on the queue is emptied earlier, the inner batches find room for 52 and more (C2 93.9 -> 92.1 ms,
-                          veach-mis spp 256 90.6 -> 89.4; 40 / 56 / 32: 91.9 / 92.9 / 92.0 and 89.6 / 89.5 / 90.8) */
+#define LEAFQ_FIRST 48 /* DEC: with this many entries the leaf queue goes before everything else: the queue is emptied early and stays far from full
+                          (when inner batches were still cut to a quarter of its free entries: C2 93.9 -> 92.1 ms, veach-mis spp 256 90.6 -> 89.4;
+                          40 / 56 / 32: 91.9 / 92.9 / 92.0 and 89.6 / 89.5 / 90.8; with full batches 32 / 40 / 56 against 48: within 0.5 %) */
 #endif
             const int nl_ = DEC ? (int)(lq_t - lq_h) : qn[PH3_LEAF];
             const int kL = ((DEC && nl_ >= LEAFQ_FIRST) ? 64 : min(nl_, 64)) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
@@ -1086,8 +1101,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             // The whole step, the appends to the leaf queue and to the inner ring included, runs under the mask of the batch's lanes
             // (a ballot there sees those lanes only); what the appends add to the wave-uniform cursors comes out of the region in a
             // vector register of lane 0, which is always one of them.
-            const int room = (int)((uint32_t)LEAFQ_CAP - (lq_t - lq_h)) >> 2;
-            const int take = min(min(64, qn[PH3_INNER]), room);
+            // (the batch is not cut to the quarter of the free queue entries that could take four entries per ray: the entries of a visit
+            // are counted before any is written, and should they not fit -- rarely: a ray adds 0.8 on average -- the lanes beyond that quarter are
+            // taken out of the visit again and queued as they came, inner4_step_dec.  Batches 57 -> 62 rays: C2 80.4 -> 79.5 ms, veach 80.4 -> 79.2)
+            const int take = min(64, qn[PH3_INNER]);
             if (STATS) { dg_b[PH3_INNER]++; dg_l[PH3_INNER] += (uint32_t)take; }
             const bool on = lane < take;
             const uint32_t id = S.rq(PH3_INNER)[ring_wrap<QCAP>((uint32_t)(qh[PH3_INNER] + lane))];
@@ -1114,8 +1131,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     // (a lane that does not take the step -- see inner4_step_dec -- keeps its node, depth and `done`)
                     const bool en = go && !ex;
                     int ref4 = ref, sp4 = sp;
-                    const bool done4 = inner4_step_dec<STATS>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en);
-                    if (en) { ref = ref4; sp = sp4; done = done4; }
+                    bool voided = false;
+                    const bool done4 = inner4_step_dec<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
+                                                                       (uint32_t)LEAFQ_CAP - (lq_t - lq_h) - (MAY_EXACT ? 64u : 0u), nullptr, &voided);
+                    // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
+                    if (en && !voided) { ref = ref4; sp = sp4; done = done4; }
+                    // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
+                    // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
+                    // least VISIT2_MIN lanes go on; its leaf entries are counted before anything is written, and if the queue cannot take
+                    // them the visit is dropped.  C2 82.7 -> 81.7 ms, veach-mis spp 256
+                    // 81.8 -> 80.3 (40 .. 52: the same; 16 / 32: 82.6 / 82.1 and 80.8 / 80.6; as a loop, or three / four visits: worse).
+                    if (!MAY_EXACT) {
+                        constexpr int VISIT2_MIN = 44;
+                        const bool en2 = go && !done;
+                        if ((int)__popcll(__builtin_amdgcn_ballot_w64(en2)) >= VISIT2_MIN) {
+                            const uint32_t cap_left = (uint32_t)LEAFQ_CAP - ((lq_t + added) - lq_h);
+                            bool bailed = false, any2 = false;
+                            uint32_t n2 = 0;
+                            int ref5 = ref, sp5 = sp;
+                            const bool done5 = inner4_step_dec<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
+                            if (!bailed && en2) { ref = ref5; sp = sp5; done = done5; n_leaf += n2; any_leaf = any_leaf | any2; }
+                        }
+                    }
                 }
                 if (MAY_EXACT) {
                     if (__builtin_amdgcn_ballot_w64(go && ex)) { // reference arithmetic on the reference topology, one thing per visit:
