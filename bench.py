@@ -23,15 +23,18 @@ roofline -- dominant kernel k_mega3 (persistent path-tracing megakernel, one lau
 measured live (HIP events on the launching stream); the counts it is set against come from rocprofv3 PMC passes of
 the same workload, kept in profiles/pmc_latest.json and STAMPED with a hash of the kernel sources and build flags:
 when the hash differs from the library that is running (or CRT_LIB_PATH loads another library), the counter-based
-fields are null (never a stale number).  Three candidate bounds are priced against DATASHEET peaks only
-(MI355X_MICROARCH.md), every fraction <= 1, and the largest is `roofline.frac` / `roofline.bound`:
-    hbm        memory-side bytes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, corrected as the guide prescribes) / t
-               against 8 TB/s; `frac_without_x2` beside it (the x2 is exact for wide streaming reads only);
-    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / 2 (the guide's 2 cycles per wave64 instruction).  Beside it, NOT
-               used to pick the bound: `frac_at_mix_cost` (the same count priced with the cycles per instruction of THIS
-               kernel's opcode mix: the exact census of tools/bbprof x the per-opcode costs of tools/valu_issue_gen.py),
-               `valu_busy_hw` (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles: how busy the vector pipes were, by the hardware's own
-               counter) and `arith_share` (share of the vector instructions that are box / triangle arithmetic);
+fields are null (never a stale number).  Three candidates are priced against DATASHEET peaks only (MI355X_MICROARCH.md); each
+fraction is reported as measured (`frac_raw`) and clamped to 1 (`frac`), a raw value above 1 is flagged `suspect` and cannot name the
+bound; `roofline.bound` is the unit that is busiest BY THE HARDWARE'S OWN COUNTERS (pick_bound):
+    memory_side  bytes that cross the L2's fabric side (32 x the TCC_EA0_*_DRAM_32B request counters: exact; or 2 x FETCH_SIZE +
+               WRITE_SIZE when only those were collected) / t against the 8 TB/s HBM peak.  NOT HBM bytes: those counters sit in
+               front of the Infinity Cache and count what it answers, no counter behind it is exposed, and this kernel's whole
+               resident set fits that cache -- the figure is path-state traffic between the XCDs' L2s and the memory side;
+    valu_issue SQ_INSTS_VALU / t against SIMDs x clock / 2 (the guide's 2 cycles per wave64 instruction) as `frac`; what enters the
+               choice of the bound is `valu_busy_hw` (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles: how busy the vector pipes were, by the
+               hardware's own counter).  Beside them: `frac_at_mix_cost` (the count priced with the cycles per instruction of THIS
+               kernel's opcode mix: the exact census of tools/bbprof x the per-opcode costs of tools/valu_issue_gen.py) and
+               `arith_share` (share of the vector instructions that are box / triangle arithmetic);
     l2         TCC requests x 128 B / t against the L2 peak.
 The SURVEY 8(d) contract figure -- algorithmic bytes of the REFERENCE traversal's visit set, B_ray = 64 x inner
 visits + 8 x leaf visits + 36 x triangle tests + 16 x hits, counted by the exhaustive kernel on a spp=8 slice --
@@ -184,28 +187,52 @@ def load_census(workload_key):
 
 
 def bounds_from_pmc(pmc, k_s, census=None):
-    """The candidate bounds for one launch of duration k_s seconds, each against a datasheet peak (MI355X_MICROARCH.md) and clamped to
-    1.  census (tools/bbprof): exact dynamic opcode counts priced with measured per-opcode issue costs -- side fields only."""
+    """The candidate bounds for one launch of duration k_s seconds, each against a datasheet peak (MI355X_MICROARCH.md).  A fraction is
+    reported as measured (`frac_raw`) beside the value clamped to 1 (`frac`); a raw value above 1 means a wrong peak, a miscounted
+    counter or a time / counter mismatch and is flagged `suspect` -- such a candidate never names the bound.
+    census (tools/bbprof): exact dynamic opcode counts priced with measured per-opcode issue costs -- side fields only."""
     out = {}
 
     def frac(x):
         return round(min(1.0, x), 4)
+
+    def put_frac(d, x, key="frac"):
+        d[key] = frac(x)
+        d[key + "_raw"] = round(x, 4)
+        if x > 1.0:
+            d["suspect"] = True
     if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+        # What crosses the L2's fabric side per launch.  NOT HBM bytes: these counters sit in front of the Infinity Cache and count what
+        # it answers (MI355X_MICROARCH.md "HBM"); rocprofv3 on this part exposes no counter behind it (rocprofv3 --list-avail, round 5), and
+        # this kernel's resident set (scene 3.6 MB + path-state planes 42 MB + the records in use) fits that cache 5 times over.  Priced
+        # against the HBM peak all the same -- the only datasheet number for that side of the chip -- and named for what it is.
         traffic = 2.0 * pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
         plain = pmc["FETCH_SIZE"] * 1024.0 + pmc["WRITE_SIZE"] * 1024.0
-        out["hbm"] = {"achieved": round(traffic / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                      "frac": frac(traffic / k_s / 1e9 / HBM_PEAK_GBPS), "bytes_per_launch": traffic,
-                      "frac_without_x2": frac(plain / k_s / 1e9 / HBM_PEAK_GBPS), "bytes_per_launch_without_x2": plain,
-                      "note": "2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950; the x2 is exact for wide streaming reads, "
-                              "this kernel's reads are 16-byte gathers: the truth lies between the two fractions"}
+        exact = None
+        if pmc.get("fabric_read_bytes") is not None and pmc.get("fabric_write_bytes") is not None:
+            exact = pmc["fabric_read_bytes"] + pmc["fabric_write_bytes"]   # 32-byte units counted as such (TCC_EA0_*_DRAM_32B): no assumed request size
+        use = exact if exact is not None else traffic
+        m = {"achieved": round(use / k_s / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "bytes_per_launch": use,
+             "bytes_source": "32 x (TCC_EA0_RDREQ_DRAM_32B + TCC_EA0_WRREQ_WRITE_DRAM_32B + TCC_EA0_WRREQ_ATOMIC_DRAM_32B)" if exact is not None
+                             else "2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction, exact for wide streaming reads only)",
+             "by_fetch_write_size": {"bytes_x2": traffic, "bytes_without_x2": plain,
+                                     "frac_x2": frac(traffic / k_s / 1e9 / HBM_PEAK_GBPS), "frac_without_x2": frac(plain / k_s / 1e9 / HBM_PEAK_GBPS)},
+             "note": "L2 <-> fabric traffic (Infinity-Cache hits included), not DRAM traffic: what the XCDs' L2s exchange with the memory side, "
+                     "i.e. path state that does not fit 8 x 4 MB of L2"}
+        if exact is not None:
+            m["read_bytes"] = pmc["fabric_read_bytes"]; m["write_bytes"] = pmc["fabric_write_bytes"]
+            m["read_bytes_per_request"] = pmc.get("fabric_read_bytes_per_request")
+        put_frac(m, use / k_s / 1e9 / HBM_PEAK_GBPS)
+        out["memory_side"] = m
     if pmc.get("SQ_INSTS_VALU") is not None:
         peak = N_SIMDS * CLOCK_GHZ / GUIDE_VALU_CYCLES
         ach = pmc["SQ_INSTS_VALU"] / k_s / 1e9
-        v = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s", "frac": frac(ach / peak),
+        v = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
              "peak_note": "SIMDs x clock / 2 cycles per wave64 instruction (the guide's figure)", "lane_utilization": pmc.get("valu_lane_utilization")}
+        put_frac(v, ach / peak)
         if pmc.get("SQ_ACTIVE_INST_VALU") is not None:
             # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's vector pipe executed: x 4 / (SIMDs x clock x t)
-            v["valu_busy_hw"] = frac(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * CLOCK_GHZ * 1e9 * k_s))
+            put_frac(v, pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * CLOCK_GHZ * 1e9 * k_s), "valu_busy_hw")
         if census:
             cyc = float(census["cycles_per_valu"])
             v["frac_at_mix_cost"] = frac(ach * cyc / (N_SIMDS * CLOCK_GHZ))
@@ -226,8 +253,23 @@ def bounds_from_pmc(pmc, k_s, census=None):
         if req is None:
             req = pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"]
         ach = req * 128.0 / k_s / 1e9
-        out["l2"] = {"achieved": round(ach, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": frac(ach / L2_PEAK_GBPS)}
+        out["l2"] = {"achieved": round(ach, 1), "peak": L2_PEAK_GBPS, "unit": "GB/s"}
+        put_frac(out["l2"], ach / L2_PEAK_GBPS)
     return out
+
+
+def pick_bound(bounds):
+    """The unit that is busiest by the hardware's own account names the bound: for the vector pipes that is `valu_busy_hw` (cycles in
+    which a SIMD's vector unit executed / all SIMD cycles -- a counter, not a priced instruction mix), for the memory side and L2 their
+    bytes against the datasheet peak.  A candidate whose raw fraction exceeds 1 is suspect and cannot win."""
+    best, best_f = None, -1.0
+    for name, b in bounds.items():
+        if b.get("suspect"):
+            continue
+        f = b.get("valu_busy_hw", b["frac"]) if name == "valu_issue" else b["frac"]
+        if f > best_f:
+            best, best_f = name, f
+    return best, best_f
 
 
 def main_rank(args):
@@ -450,16 +492,22 @@ def main_rank(args):
             bounds = bounds_from_pmc(pmc, k_ms * 1e-3, load_census(wl))
             roofline["bounds"] = bounds
             if bounds:
-                name = max(bounds, key=lambda b: bounds[b]["frac"])
-                roofline.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
-                                 "unit": bounds[name]["unit"], "frac": bounds[name]["frac"]})
-            if "hbm" in bounds:
-                roofline["traffic"] = bounds["hbm"]["bytes_per_launch"]
+                name, f = pick_bound(bounds)
+                if name == "valu_issue" and "valu_busy_hw" in bounds[name]:
+                    # the vector pipes' busy cycles against all SIMD cycles (the hardware's counter): achieved / peak in SIMD-cycles per second
+                    roofline.update({"bound": name, "achieved": round(f * N_SIMDS * CLOCK_GHZ, 1), "peak": round(N_SIMDS * CLOCK_GHZ, 1),
+                                     "unit": "G SIMD-cycles/s busy (SQ_ACTIVE_INST_VALU x 4)", "frac": f})
+                elif name is not None:
+                    roofline.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
+                                     "unit": bounds[name]["unit"], "frac": bounds[name]["frac"]})
+            if "memory_side" in bounds:
+                roofline["traffic"] = bounds["memory_side"]["bytes_per_launch"]
+                roofline["traffic_note"] = "L2 <-> fabric bytes (Infinity-Cache hits included; no DRAM-only counter is exposed): bounds.memory_side"
             roofline["pmc"] = {"src_hash": B.source_hash(), "collected": pmc.get("collected"), "profiled_launch_ms": pmc.get("avg_launch_ms"),
                                "salu_per_valu": pmc.get("salu_per_valu"), "wait_any_frac": pmc.get("SQ_WAIT_ANY/WAVE_CYCLES"),
                                "tcc_miss_frac": pmc.get("tcc_miss_frac")}
             roofline["note"] = ("counts from rocprofv3 --pmc passes of this exact workload and code (hash-stamped), time from HIP events of this "
-                                "run; every fraction is against a datasheet peak (MI355X_MICROARCH.md) and the largest names the bound.  The "
+                                "run; every fraction is against a datasheet peak (MI355X_MICROARCH.md); the unit that is busiest by the hardware's own counters names the bound (pick_bound).  The "
                                 "kernel is co-limited: its vector pipes are `bounds.valu_issue.valu_busy_hw` busy (the hardware's counter) "
                                 "executing an opcode mix that costs `mix_cycles_per_instr` cycles per instruction instead of the guide's 2, "
                                 "`arith_share` of those instructions are box / triangle arithmetic; its waves wait on memory `pmc.wait_any_frac` "
@@ -634,8 +682,8 @@ def main_rank(args):
                                              task.light_sample_n, seed=args.seed)
             cdt = time.perf_counter() - c0
             cpu = {"value": round(ost["rays"] / cdt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                   "sample": "%s %dx%d spp=%d (%d paths, %d rays) in %.1f s, single thread"
-                             % (args.scene, args.width, args.height, args.cpu_spp, ost["paths"], ost["rays"], cdt),
+                   "sample": "%s %dx%d spp=%d = %d x BASELINE config C1 (the same frame at spp=2: a superset of it) (%d paths, %d rays) in %.1f s, single thread"
+                             % (args.scene, args.width, args.height, args.cpu_spp, args.cpu_spp // 2, ost["paths"], ost["rays"], cdt),
                    "ms_per_frame_extrapolated": round(cdt * 1e3 * args.spp / args.cpu_spp, 1)}
             render.set_spp(args.cpu_spp)
             render.traversal = trav

@@ -103,11 +103,23 @@ class _BuildLock:
         self.f.close()
 
 
+def _obj_flags(obj):
+    try:
+        with open(obj + ".flags") as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def _compile_one(src, obj, verbose):
     cmd = [HIPCC] + COMMON + DEVICE + ["-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(obj + ".flags"):
+        os.remove(obj + ".flags")  # (an interrupted compile leaves no object that claims these flags)
     subprocess.check_call(cmd)
+    with open(obj + ".flags", "w") as f:  # the flags THIS object was compiled with: an interrupted flag-change build cannot link mixed objects
+        f.write(flags_string() + "\n")
 
 
 def build_lib(force=False, verbose=False):
@@ -127,7 +139,7 @@ def build_lib(force=False, verbose=False):
         for s in LIB_SOURCES:
             obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
             objs.append(obj)
-            if flags_changed or _stale(obj, [s] + headers):
+            if flags_changed or _obj_flags(obj) != flags_string() or _stale(obj, [s] + headers):
                 jobs.append((s, obj))
         with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
             for f in [ex.submit(_compile_one, s, o, verbose) for s, o in jobs]:

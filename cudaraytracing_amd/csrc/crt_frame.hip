@@ -43,10 +43,17 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
         if (!A.first_chunk) c = f3(acc_load(A.accum + slot), acc_load(A.accum + A.nslots + slot), acc_load(A.accum + 2ull * A.nslots + slot));
         const float fspp = (float)A.spp;
         for (uint32_t s = 0; s < A.chunk_samples; s++) { // temp_color += L / spp, in sample order (Render.cuh:348)
-            float4 l = A.L[(uint64_t)s * A.nslots + slot];
-            c.x = c.x + l.x / fspp;
-            c.y = c.y + l.y / fspp;
-            c.z = c.z + l.z / fspp;
+            // (agent-scope loads: the radiance was written by the launch before this one, from other XCDs -- the same kind of hand-off as
+            // k_order_items -> k_mega3, whose plain loads were seen to return what an earlier kernel had left at the address)
+            const float* lp = (const float*)&A.L[(uint64_t)s * A.nslots + slot];
+#ifdef CRT_ACCUM_PLAIN
+            const float lx = lp[0], ly = lp[1], lz = lp[2];
+#else
+            const float lx = acc_load(lp), ly = acc_load(lp + 1), lz = acc_load(lp + 2);
+#endif
+            c.x = c.x + lx / fspp;
+            c.y = c.y + ly / fspp;
+            c.z = c.z + lz / fspp;
         }
         if (!A.last_chunk) {
             acc_store(A.accum + slot, c.x); acc_store(A.accum + A.nslots + slot, c.y); acc_store(A.accum + 2ull * A.nslots + slot, c.z);

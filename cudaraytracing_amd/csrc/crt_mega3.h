@@ -76,12 +76,25 @@ struct MParams {
 #define RF_HASHIT 0x20000000u  /* closest-hit ray: a hit is recorded (T = its distance) */
 #define RF_SKIP 0x40000000u    /* (NewRay only) next-event sample with a zero contribution: answered without traversal */
 #define RF_QUERY 0x80000000u   /* crt_intersect: a bare closest-hit query; its result goes straight back to LC */
+#ifndef CRT_RING_MODE
+#define CRT_RING_MODE 2 /* 2: the rings are STACKS -- a batch is the newest ids, one scalar per ring, no wrap (round 5: C2 -1.3 %, veach-mis -1.1 % on top of
+                           the mask form of the inner step); 0: FIFO rings that wrap by compare (rounds 2 - 4); 1: FIFO rings of 256 entries, wrap by mask,
+                           146 rays per wave (measured: +0.5 % / +0.1 % against 0 -- the smaller pool costs what the mask saves) (crt_mega3.hip: ring_wrap) */
+#endif
 #ifndef POOL3_P
+#if CRT_RING_MODE == 1
+#define POOL3_P 154
+#else
 #define POOL3_P 164         /* 164 x 56 B + rings = 10 004 B: 16 waves per CU (measured with the 16-bit stack layout: 148 rays x 64 B records
                                with 1/d and six levels 102.5 ms, 176 x 52 B with six levels 100.2, 164 x 56 B with eight levels 98.8, 156 x 60 B with
                                ten 100.0) */
 #endif
+#endif
+#if CRT_RING_MODE == 1
+#define POOL3_QCAP 256
+#else
 #define POOL3_QCAP ((POOL3_P + 3) & ~3) /* ring capacity (any number >= POOL3_P: indices wrap by compare, not by mask); ids fit a byte */
+#endif
 static_assert(POOL3_P <= 256, "ray ids of a pool must fit a byte (ring entries are uint8_t)");
 static_assert(POOL3_QCAP >= POOL3_P, "a ring must hold every ray of the pool");
 #define CRT_MEGA3_MAX_STACK 255 /* the traversal stack depth is kept in 8 bits of the record's word D */
@@ -142,9 +155,9 @@ struct Pool4LdsT {
 #ifdef POOL4_P
     static constexpr int P = POOL4_P;
 #else
-    static constexpr int P = RING_ ? 148 : 152;
+    static constexpr int P = CRT_RING_MODE == 1 ? (RING_ ? 140 : 146) : (RING_ ? 148 : 152);
 #endif
-    static constexpr int QCAP = (P + 3) & ~3;
+    static constexpr int QCAP = CRT_RING_MODE == 1 ? 256 : (P + 3) & ~3;
 #ifdef POOL4_LV
     static constexpr int LV = R16_ ? POOL4_LV : POOL4_LV / 2;
 #else

@@ -8,6 +8,10 @@
 #include <cstring>
 #include <vector>
 
+#ifndef CRT_X_BOOLMASK
+#define CRT_X_BOOLMASK 1 /* decoupled inner step: the children's accept tests and everything derived from them as wave masks in scalar registers (round 5; 0 = the round-4 form) */
+#endif
+
 namespace crtk {
 
 struct NewRay {
@@ -30,8 +34,38 @@ __device__ __forceinline__ int smax(const int a, const int b)
 }
 
 // Ring index in [0, 2 * QCAP) -> [0, QCAP).
+// (CRT_RING_MODE 1: rings of 256 entries, the wrap is a mask; 2: the rings are stacks -- a batch is the NEWEST ids, no head, no tail, no wrap)
 template <int QCAP>
-__device__ __forceinline__ uint32_t ring_wrap(const uint32_t x) { return min(x, x - (uint32_t)QCAP); }
+__device__ __forceinline__ uint32_t ring_wrap(const uint32_t x)
+{
+#if CRT_RING_MODE == 1
+    static_assert(QCAP == 256, "CRT_RING_MODE 1: rings of 256 entries");
+    return x & 255u;
+#elif CRT_RING_MODE == 2
+    return x;
+#else
+    return min(x, x - (uint32_t)QCAP);
+#endif
+}
+#if CRT_RING_MODE == 2
+// (the count doubles as the place of the next id, i.e. as the addend of v_mbcnt, a vector operand: handed over as a scalar COPY, or the
+// compiler moves the count itself into a vector register, where the scheduler's scalar maxima cannot reach it)
+__device__ __forceinline__ uint32_t scalar_copy(int x) { asm volatile("" : "+s"(x)); return (uint32_t)x; }
+#define RQ_PUSH_BASE(p_) (STATS ? (uint32_t)qn[p_] : scalar_copy(qn[p_])) /* where the next id goes (the counting kernels keep more scalars: theirs may live in vector registers) */
+#define RQ_PUSH_ADV(p_, n_) { qn[p_] += (n_); }
+#define RQ_POP_BASE(p_, take_) ((uint32_t)(qn[p_] - (take_)))
+#define RQ_POP_ADV(p_, take_) { qn[p_] -= (take_); }
+#else
+#define RQ_PUSH_BASE(p_) ((uint32_t)qt[p_])
+#if CRT_RING_MODE == 1
+#define RQ_PUSH_ADV(p_, n_) { qn[p_] += (n_); qt[p_] = (qt[p_] + (n_)) & 255; }
+#define RQ_POP_ADV(p_, take_) { qh[p_] = (qh[p_] + (take_)) & 255; qn[p_] -= (take_); }
+#else
+#define RQ_PUSH_ADV(p_, n_) { qn[p_] += (n_); qt[p_] += (n_); if (qt[p_] >= QCAP) qt[p_] -= QCAP; }
+#define RQ_POP_ADV(p_, take_) { qh[p_] += (take_); if (qh[p_] >= QCAP) qh[p_] -= QCAP; qn[p_] -= (take_); }
+#endif
+#define RQ_POP_BASE(p_, take_) ((uint32_t)qh[p_])
+#endif
 
 // Where a ray goes once its traversal is over: a next-event sample to LA (LB after the last one of its vertex), a probe
 // or a closest-hit ray that found a surface to LA, a closest-hit ray that found nothing to LC.
@@ -416,7 +450,11 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
                 // (agent-scope load, as k_order_items' stores: with plain accesses the FIRST frame of a render created after other renders of
                 // the process came out with 10 - 400 work items of the 589 824 of a 96 x 64 x 96 frame never run -- their list entries read as
                 // what an earlier kernel had left at the address -- in half of the runs once the launches' timing had changed)
+#if defined(CRT_HANDOFF_PLAIN) || defined(CRT_HANDOFF_PLAIN_LOAD) /* experiment builds only (tools/handoff_ab.sh): the accesses as they were */
+                if (item >= wlo_) item = ((CRT_GAS const unsigned int*)P.item_list)[sh_ * P.order_window + (item - wlo_)];
+#else
                 if (item >= wlo_) item = __hip_atomic_load((CRT_GAS const unsigned int*)&P.item_list[sh_ * P.order_window + (item - wlo_)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
         }
         bool valid; uint32_t pi, pj, pixel_index, k;
@@ -534,6 +572,28 @@ __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 f
         t2 = ((e2 <= x2 + CRT_EPSILON) & (x2 >= 0)) ? e2 : inf;
         t3 = ((e3 <= x3 + CRT_EPSILON) & (x3 >= 0)) ? e3 : inf;
     }
+}
+
+// The same four boxes with the accept test of hit_AABB (DeviceBVH.cuh:121-125) handed back as predicates beside the entry distances:
+// the decoupled step needs "hit" as a wave mask (its leaf-queue appends) and as a lane predicate, and the distance only to put the
+// nearest inner child first -- a distance forced to +inf and compared with +inf again costs a select and a compare per child.
+__device__ __forceinline__ void slab_quad_hits(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
+                                               const F3 o, const F3 inv, float& e0, float& e1, float& e2, float& e3,
+                                               unsigned long long& h0, unsigned long long& h1, unsigned long long& h2, unsigned long long& h3)
+{
+    const v2f nxa = (v2(nx.x, nx.y) - v2s(o.x)) * v2s(inv.x), nxb = (v2(nx.z, nx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f nya = (v2(ny.x, ny.y) - v2s(o.y)) * v2s(inv.y), nyb = (v2(ny.z, ny.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f nza = (v2(nz.x, nz.y) - v2s(o.z)) * v2s(inv.z), nzb = (v2(nz.z, nz.w) - v2s(o.z)) * v2s(inv.z);
+    const v2f fxa = (v2(fx.x, fx.y) - v2s(o.x)) * v2s(inv.x), fxb = (v2(fx.z, fx.w) - v2s(o.x)) * v2s(inv.x);
+    const v2f fya = (v2(fy.x, fy.y) - v2s(o.y)) * v2s(inv.y), fyb = (v2(fy.z, fy.w) - v2s(o.y)) * v2s(inv.y);
+    const v2f fza = (v2(fz.x, fz.y) - v2s(o.z)) * v2s(inv.z), fzb = (v2(fz.z, fz.w) - v2s(o.z)) * v2s(inv.z);
+    e0 = fmax3(nxa.x, nya.x, nza.x); e1 = fmax3(nxa.y, nya.y, nza.y); e2 = fmax3(nxb.x, nyb.x, nzb.x); e3 = fmax3(nxb.y, nyb.y, nzb.y);
+    const float x0 = fmin3(fxa.x, fya.x, fza.x), x1 = fmin3(fxa.y, fya.y, fza.y), x2 = fmin3(fxb.x, fyb.x, fzb.x), x3 = fmin3(fxb.y, fyb.y, fzb.y);
+    // (a wave mask per child: the AND of the two compares' own results -- a ballot of their conjunction would cost a select and a compare)
+    h0 = __builtin_amdgcn_ballot_w64(e0 <= x0 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x0 >= 0);
+    h1 = __builtin_amdgcn_ballot_w64(e1 <= x1 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x1 >= 0);
+    h2 = __builtin_amdgcn_ballot_w64(e2 <= x2 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x2 >= 0);
+    h3 = __builtin_amdgcn_ballot_w64(e3 <= x3 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x3 >= 0);
 }
 
 // The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
@@ -739,10 +799,35 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
     const F3 inv = inv3_exact(dir);
     float t0, t1, t2, t3;
-    slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
-    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     const float inf = pinf();
     int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+#if CRT_X_BOOLMASK
+    // The accept test as predicates, and everything that follows from them as WAVE MASKS in scalar registers (a ballot of a compare is
+    // the compare's own result; ANDs, the overflow cut and the counts are scalar instructions), turned back into lane predicates
+    // where a select or a store needs one (inverse ballot: the select reads the mask as it stands).
+    unsigned long long H0, H1, H2, H3;
+    slab_quad_hits(a0, a1, a2, b0, b1, b2, o, inv, t0, t1, t2, t3, H0, H1, H2, H3);
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    const unsigned long long N0 = __builtin_amdgcn_ballot_w64(r0 < 0), N1 = __builtin_amdgcn_ballot_w64(r1 < 0), N2 = __builtin_amdgcn_ballot_w64(r2 < 0), N3 = __builtin_amdgcn_ballot_w64(r3 < 0);
+    uint32_t tail = lq_t + added;
+    unsigned long long m0 = H0 & N0, m1 = H1 & N1, m2 = H2 & N2, m3 = H3 & N3;         // leaf children that are hit
+    unsigned long long i0 = H0 & ~N0, i1 = H1 & ~N1, i2 = H2 & ~N2, i3 = H3 & ~N3;     // inner children that are hit
+    unsigned long long void_mask = 0ull;
+    if (CHECK != 0) {
+        if ((uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)) > cap_left) {
+            if (CHECK == 2) { *bailed = true; return false; }
+            // the lanes a quarter of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
+            const unsigned long long km = __builtin_amdgcn_ballot_w64((uint32_t)(threadIdx.x & 63) < (cap_left >> 2));
+            m0 &= km; m1 &= km; m2 &= km; m3 &= km;
+            i0 &= km; i1 &= km; i2 &= km; i3 &= km;
+            void_mask = ~km;
+        }
+    }
+    if (CHECK == 1) *voided = __builtin_amdgcn_inverse_ballot_w64(void_mask);
+    const bool l0 = __builtin_amdgcn_inverse_ballot_w64(m0), l1 = __builtin_amdgcn_inverse_ballot_w64(m1), l2 = __builtin_amdgcn_inverse_ballot_w64(m2), l3 = __builtin_amdgcn_inverse_ballot_w64(m3);
+#else
+    slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
+    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     // (one compare per operand, shared by the lane's predicate and the wave's mask: the mask is the AND of the two ballots)
     // (t is an entry distance of finite operands or exactly +inf, never a NaN: the integer compare is the same test, and one the
     // compiler does not rewrite differently for the predicate and for the ballot)
@@ -751,6 +836,7 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
 #define CRT_LEAF_MASK(h_, n_) (__builtin_amdgcn_ballot_w64(h_) & __builtin_amdgcn_ballot_w64(n_))
     uint32_t tail = lq_t + added;
     unsigned long long m0 = CRT_LEAF_MASK(h0, n0), m1 = CRT_LEAF_MASK(h1, n1), m2 = CRT_LEAF_MASK(h2, n2), m3 = CRT_LEAF_MASK(h3, n3);
+#undef CRT_LEAF_MASK
     bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
     if (CHECK != 0) {
         if ((uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)) > cap_left) {
@@ -764,6 +850,7 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
             *voided = !keep;
         }
     }
+#endif
     if (STATS && enable && !(CHECK == 1 && *voided)) tc.inner++;
     leafq_push_all(S, l0, m0, ((uint32_t)r0 & 0x7fffff00u) | id, tail);
     leafq_push_all(S, l1, m1, ((uint32_t)r1 & 0x7fffff00u) | id, tail);
@@ -771,9 +858,14 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     leafq_push_all(S, l3, m3, ((uint32_t)r3 & 0x7fffff00u) | id, tail);
     added = tail - lq_t;
     n_leaf = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-#undef CRT_LEAF_MASK
+#if CRT_X_BOOLMASK
+    any_leaf = __builtin_amdgcn_inverse_ballot_w64(m0 | m1 | m2 | m3);
+    t0 = __builtin_amdgcn_inverse_ballot_w64(i0) ? t0 : inf; t1 = __builtin_amdgcn_inverse_ballot_w64(i1) ? t1 : inf;
+    t2 = __builtin_amdgcn_inverse_ballot_w64(i2) ? t2 : inf; t3 = __builtin_amdgcn_inverse_ballot_w64(i3) ? t3 : inf;
+#else
     any_leaf = l0 | l1 | l2 | l3;
     t0 = n0 ? inf : t0; t1 = n1 ? inf : t1; t2 = n2 ? inf : t2; t3 = n3 ? inf : t3;
+#endif
 #define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
 #ifndef CRT_DEC_UNSORTED
     CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2)
@@ -878,18 +970,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     for (int p = 0; p < PH3_N; p++) { qn[p] = 0; qh[p] = 0; qt[p] = 0; }
     uint32_t dg_b[5] = {0, 0, 0, 0, 0}, dg_l[5] = {0, 0, 0, 0, 0}; // STATS: batches and rays per phase
     uint32_t dg_sp[6] = {0, 0, 0, 0, 0, 0};                         // STATS, per lane: inner steps that leave the stack deeper than 1 .. 6 entries
+    uint32_t dg_ov[2] = {0, 0};                                     // STATS, per lane (DEC): visits taken back because the leaf queue was full (first visit: voided lanes; second visit: bailed, counted by its lanes)
     uint32_t lq_h = 0, lq_t = 0; // DEC: the leaf queue's head and tail, free-running (entries = tail - head, index = counter mod LEAFQ_CAP)
     constexpr bool commit_ring = RING;
+#ifdef CRT_HANDOFF_INV /* experiment builds only: what a dispatch's agent-scope acquire does, by hand (vector L1 and the non-local lines of L2) */
+    asm volatile("buffer_inv sc1" ::: "memory");
+#endif
+#ifdef CRT_HANDOFF_INV_SYS
+    asm volatile("buffer_inv sc0 sc1" ::: "memory");
+#endif
     if (commit_ring && lane == 0) S.waitq = 0u;
     // every ray of the pool starts in LC with a path in stage NEW
     {
-        const int n_valid = (int)min((uint32_t)LDS3::P, pl.n > base ? pl.n - base : 0u);
+        // (readfirstlane: the value is wave-uniform, and left to itself the compiler may compute it -- and the LC ring's count that starts
+        // from it -- in a vector register, which the scalar maxima of the scheduler cannot take)
+        const int n_valid = __builtin_amdgcn_readfirstlane((int)min((uint32_t)LDS3::P, pl.n > base ? pl.n - base : 0u));
         for (int i = lane; i < n_valid; i += 64) {
             S.rq(PH3_LC)[i] = (uint8_t)i;
             pl.la[base + i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_NEW << 8));
         }
         qn[PH3_LC] = n_valid;
         qt[PH3_LC] = n_valid >= QCAP ? n_valid - QCAP : n_valid;
+        (void)qh; (void)qt;
     }
 
 // appends the processed rays (lane active = `on`, ray `id`) to the ring of their new phase
@@ -899,12 +1001,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         const unsigned long long m = __ballot(mine);                                                                       \
         if (m) {                                                                                                           \
             /* slot = tail + number of lanes below this one that go the same way: the tail rides in as mbcnt's addend */      \
-            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qt[p])); \
+            const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, RQ_PUSH_BASE(p))); \
             if (mine) S.rq(p)[ring_wrap<QCAP>(slot)] = (uint8_t)id;                                                            \
             const int add = (int)__popcll(m);                                                                              \
-            qn[p] += add;                                                                                                  \
-            qt[p] += add;                                                                                                  \
-            if (qt[p] >= QCAP) qt[p] -= QCAP;                                                                  \
+            RQ_PUSH_ADV(p, add)                                                                                            \
         }                                                                                                                  \
     }
 // after a traversal step: a ray goes on to an inner node or a leaf, or it is finished -- only then (one wave-uniform test
@@ -915,10 +1015,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     const int take = min(64, qn[p]);                                                                                       \
     if (STATS) { dg_b[p]++; dg_l[p] += (uint32_t)take; }                                                                   \
     const bool on = lane < take;                                                                                           \
-    const uint32_t id = S.rq(p)[ring_wrap<QCAP>((uint32_t)(qh[p] + lane))];                                                    \
-    qh[p] += take;                                                                                                         \
-    if (qh[p] >= QCAP) qh[p] -= QCAP;                                                                          \
-    qn[p] -= take;                                                                                                         \
+    const uint32_t id = S.rq(p)[ring_wrap<QCAP>(RQ_POP_BASE(p, take) + (uint32_t)lane)];                                       \
+    RQ_POP_ADV(p, take)                                                                                                    \
     const uint32_t g = base + id;                                                                                          \
     uint32_t nph = PH3_NONE;
 
@@ -956,6 +1054,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                           (when inner batches were still cut to a quarter of its free entries: C2 93.9 -> 92.1 ms, veach-mis spp 256 90.6 -> 89.4;
                           40 / 56 / 32: 91.9 / 92.9 / 92.0 and 89.6 / 89.5 / 90.8; with full batches 32 / 40 / 56 against 48: within 0.5 %) */
 #endif
+            // (an inner step starts with fewer than LEAFQ_FIRST entries in the queue -- from that many on the leaf step goes first, here and
+            // in the alternating loop -- and must find room for a reference-arithmetic batch, 64 entries appended outside the counted
+            // ones, plus four entries, the least a 4-wide visit needs to keep one lane: otherwise it would take every lane back, for ever)
+            static_assert(LEAFQ_FIRST >= 1 && LEAFQ_FIRST + 64 + 4 <= LEAFQ_CAP, "leaf queue: LEAFQ_FIRST - 1 entries + a reference-arithmetic batch + one lane's four entries must fit LEAFQ_CAP");
             const int nl_ = DEC ? (int)(lq_t - lq_h) : qn[PH3_LEAF];
             const int kL = ((DEC && nl_ >= LEAFQ_FIRST) ? 64 : min(nl_, 64)) * 8 + PH3_LEAF, kI = min(qn[PH3_INNER], 64) * 8 + PH3_INNER;
             // (s_max_i32 by hand: the compiler folds nested maxima of wave-uniform values into v_max3_i32 -- a vector instruction, plus
@@ -1086,12 +1188,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         const bool mine_ = (cond_);                                                                                        \
         const unsigned long long m_ = __builtin_amdgcn_ballot_w64(mine_);                                                  \
         if (m_) {                                                                                                          \
-            const uint32_t slot_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, (uint32_t)qt[p_])); \
+            const uint32_t slot_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_, RQ_PUSH_BASE(p_))); \
             if (mine_) S.rq(p_)[ring_wrap<QCAP>(slot_)] = (uint8_t)id;                                                     \
             const int add_ = (int)__popcll(m_);                                                                            \
-            qn[p_] += add_;                                                                                                \
-            qt[p_] += add_;                                                                                                \
-            if (qt[p_] >= QCAP) qt[p_] -= QCAP;                                                                            \
+            RQ_PUSH_ADV(p_, add_)                                                                                          \
         }                                                                                                                  \
     }
         auto inner_arm_dec = [&](auto may_exact_) __attribute__((always_inline)) {
@@ -1107,10 +1207,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             const int take = min(64, qn[PH3_INNER]);
             if (STATS) { dg_b[PH3_INNER]++; dg_l[PH3_INNER] += (uint32_t)take; }
             const bool on = lane < take;
-            const uint32_t id = S.rq(PH3_INNER)[ring_wrap<QCAP>((uint32_t)(qh[PH3_INNER] + lane))];
-            qh[PH3_INNER] += take;
-            if (qh[PH3_INNER] >= QCAP) qh[PH3_INNER] -= QCAP;
-            qn[PH3_INNER] -= take;
+            const uint32_t id = S.rq(PH3_INNER)[ring_wrap<QCAP>(RQ_POP_BASE(PH3_INNER, take) + (uint32_t)lane)];
+            RQ_POP_ADV(PH3_INNER, take)
             const uint32_t g = base + id;
             uint32_t xfer = 0;            // entries appended to the leaf queue | rays re-queued << 16 | rays of the reference-arithmetic path that ended << 24
             uint32_t nph = PH3_NONE;      // a ray that is complete (its walk is over and none of its entries is in flight): where it goes
@@ -1132,25 +1230,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const bool en = go && !ex;
                     int ref4 = ref, sp4 = sp;
                     bool voided = false;
+                    // (free entries, saturating: the scheduler drains the queue from LEAFQ_FIRST entries on and a step adds at most what is
+                    // free, so the difference cannot be negative -- but a wrapped unsigned here would switch the overflow check off for good)
+                    const uint32_t lq_used = (lq_t - lq_h) + (MAY_EXACT ? 64u : 0u);
+                    const uint32_t lq_free = lq_used < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used : 0u;
                     const bool done4 = inner4_step_dec<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
-                                                                       (uint32_t)LEAFQ_CAP - (lq_t - lq_h) - (MAY_EXACT ? 64u : 0u), nullptr, &voided);
+                                                                       lq_free, nullptr, &voided);
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
                     if (en && !voided) { ref = ref4; sp = sp4; done = done4; }
+                    if (STATS && en && voided) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
                     // least VISIT2_MIN lanes go on; its leaf entries are counted before anything is written, and if the queue cannot take
                     // them the visit is dropped.  C2 82.7 -> 81.7 ms, veach-mis spp 256
                     // 81.8 -> 80.3 (40 .. 52: the same; 16 / 32: 82.6 / 82.1 and 80.8 / 80.6; as a loop, or three / four visits: worse).
                     if (!MAY_EXACT) {
-                        constexpr int VISIT2_MIN = 44;
+#ifndef CRT_VISIT2_MIN
+#define CRT_VISIT2_MIN 44
+#endif
+                        constexpr int VISIT2_MIN = CRT_VISIT2_MIN;
                         const bool en2 = go && !done;
                         if ((int)__popcll(__builtin_amdgcn_ballot_w64(en2)) >= VISIT2_MIN) {
-                            const uint32_t cap_left = (uint32_t)LEAFQ_CAP - ((lq_t + added) - lq_h);
+                            const uint32_t lq_used2 = (lq_t + added) - lq_h;
+                            const uint32_t cap_left = lq_used2 < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used2 : 0u;
                             bool bailed = false, any2 = false;
                             uint32_t n2 = 0;
                             int ref5 = ref, sp5 = sp;
                             const bool done5 = inner4_step_dec<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
                             if (!bailed && en2) { ref = ref5; sp = sp5; done = done5; n_leaf += n2; any_leaf = any_leaf | any2; }
+                            if (STATS && bailed && en2) dg_ov[1]++;
                         }
                     }
                 }
@@ -1179,7 +1287,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 // re-queue the rays that go on
                 const unsigned long long mc = __builtin_amdgcn_ballot_w64(!done);
                 if (mc) {
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, (uint32_t)qt[PH3_INNER]));
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, RQ_PUSH_BASE(PH3_INNER)));
                     if (!done) S.rq(PH3_INNER)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
                 }
                 xfer = added | ((uint32_t)__popcll(mc) << 16);
@@ -1189,9 +1297,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             lq_t += xfer & 0xffffu;
             {
                 const int c = (int)((xfer >> 16) & 0xffu);
-                qn[PH3_INNER] += c;
-                qt[PH3_INNER] += c;
-                if (qt[PH3_INNER] >= QCAP) qt[PH3_INNER] -= QCAP;
+                RQ_PUSH_ADV(PH3_INNER, c)
             }
             if (MAY_EXACT) n_exact -= (int)(xfer >> 24);
             if (__builtin_amdgcn_ballot_w64(nph != PH3_NONE)) {
@@ -1269,7 +1375,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         // 89.5 -> 84.8 (32 / 52: the same).  Not taken: staying on the SAME ring while it holds another full batch (92.9 / 86.7); one chained
         // step only, each arm compiled twice (92.1 / 86.0); the same preference expressed in the scheduler's keys (no gain); a short-cut in
         // front of the scheduler (93.6 / 88.7).
-        constexpr int CHAIN_MIN = 44;
+#ifndef CRT_CHAIN_MIN
+#define CRT_CHAIN_MIN 44
+#endif
+        constexpr int CHAIN_MIN = CRT_CHAIN_MIN;
         auto logic_waits = [&]() __attribute__((always_inline)) {
             if constexpr (STATS) return max(max(qn[PH3_LA], qn[PH3_LB]), qn[PH3_LC]) >= 64; // (the counting kernels' cursors may live in vector registers)
             else return smax(smax(qn[PH3_LA], qn[PH3_LB]), qn[PH3_LC]) >= 64;
@@ -1340,7 +1449,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
-        } else {
+#ifdef CRT_CHAIN_LB_LC /* experiment: LB's roulette stops feed LC -- go there at once, without the scheduler, if LC now holds this many paths */
+            if (!commit_ring && qn[PH3_LC] >= CRT_CHAIN_LB_LC) act = PH3_LC;
+#endif
+        }
+        if (act != PH3_LA && act != PH3_LB) {
             // LC, or -- commit ring -- a look at the slots that are held back (PH3_WAIT), through the same code: the held slots have
             // their turn when the pool has nothing else to do and, while there are any, at every second visit of this phase
             // (no loop around the phase: it would count as one more level of nesting in the compiler's register allocation)
@@ -1351,15 +1464,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 wn = (int)(wq & 0xffu); wh = (int)((wq >> 8) & 0xffu); wt = (int)((wq >> 16) & 0xffu);
                 held = act == PH3_NONE || (wn > 0 && (wq >> 24) != 0u);
             }
-            const int src_n = held ? wn : qn[PH3_LC], src_h = held ? wh : qh[PH3_LC];
+            const int src_n = held ? wn : qn[PH3_LC];
             const int take = min(64, src_n);
+            const int src_h = held ? wh : (int)RQ_POP_BASE(PH3_LC, take);
             if (STATS) { dg_b[PH3_LC]++; dg_l[PH3_LC] += (uint32_t)take; }
             const bool on = lane < take;
-            const uint32_t id = (held ? S.rq(PH3_WAIT) : S.rq(PH3_LC))[ring_wrap<QCAP>((uint32_t)(src_h + lane))];
-            {
+            // (the parking ring of the commit ring is a FIFO whatever CRT_RING_MODE says: its wrap is by compare)
+            const uint32_t pop_i = (uint32_t)(src_h + lane);
+            const uint32_t id = held ? S.rq(PH3_WAIT)[min(pop_i, pop_i - (uint32_t)QCAP)] : S.rq(PH3_LC)[ring_wrap<QCAP>(pop_i)];
+            if (held) {
                 int nh = src_h + take;
                 if (nh >= QCAP) nh -= QCAP;
-                if (held) { wh = nh; wn -= take; } else { qh[PH3_LC] = nh; qn[PH3_LC] -= take; }
+                wh = nh; wn -= take;
+            } else {
+                RQ_POP_ADV(PH3_LC, take)
             }
             const uint32_t g = base + id;
             uint32_t nph = PH3_NONE;
@@ -1382,7 +1500,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const unsigned long long mw = __ballot(wait);
                 if (mw) {
                     const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, (uint32_t)wt));
-                    if (wait) S.rq(PH3_WAIT)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
+                    if (wait) S.rq(PH3_WAIT)[min(slot, slot - (uint32_t)QCAP)] = (uint8_t)id;
                     const int add = (int)__popcll(mw);
                     wn += add;
                     wt += add;
@@ -1427,6 +1545,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         for (int k = 0; k < 6; k++) {
             const uint32_t v = wave_sum(dg_sp[k]);
             if (lane == 0) atomicAdd(&cs[C_DIAG + 10 + k], (unsigned long long)v);
+        }
+        for (int k = 0; k < 2; k++) {
+            const uint32_t v = wave_sum(dg_ov[k]);
+            if (lane == 0) atomicAdd(&cs[C_DIAG + 16 + k], (unsigned long long)v);
         }
     }
 }
@@ -1483,8 +1605,13 @@ __global__ __launch_bounds__(64) void k_order_items(const LParams P, uint32_t* l
         const unsigned long long m_on = __ballot(on_j), m_off = __ballot(ex_j && !on_j);
         const unsigned long long below = (1ull << lane) - 1ull;
         const uint32_t i = b + j * 64u + lane;
+#if defined(CRT_HANDOFF_PLAIN) || defined(CRT_HANDOFF_PLAIN_STORE)
+        if (on_j) out[base_on + (uint32_t)__popcll(m_on & below)] = i;
+        else if (ex_j) out[wn - 1u - (base_off + (uint32_t)__popcll(m_off & below))] = i;
+#else
         if (on_j) __hip_atomic_store(&out[base_on + (uint32_t)__popcll(m_on & below)], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (ex_j) __hip_atomic_store(&out[wn - 1u - (base_off + (uint32_t)__popcll(m_off & below))], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         base_on += (unsigned int)__popcll(m_on);
         base_off += (unsigned int)__popcll(m_off);
     }
@@ -1497,6 +1624,12 @@ void launch_order_items(bool ring, uint32_t blocks, hipStream_t st, const LParam
     if (ring) hipLaunchKernelGGL(k_order_items<true>, dim3(blocks), dim3(64), 0, st, P, list, cnt);
     else hipLaunchKernelGGL(k_order_items<false>, dim3(blocks), dim3(64), 0, st, P, list, cnt);
 }
+#ifdef CRT_ASM_ONLY_DEFAULT /* tools/diet/asm_default.sh: the default instantiation alone (a quick assembly listing; never a library) */
+#ifndef CRT_ASM_ONLY_ARGS
+#define CRT_ASM_ONLY_ARGS 2, false, false, false, true, false, true
+#endif
+Mega3Kernel mega3_kernel(int, bool, bool, bool, bool, bool, bool) { return (Mega3Kernel)k_mega3<CRT_ASM_ONLY_ARGS>; }
+#else
 template <bool R16, bool DEC> Mega3Kernel mega3_exact_kernel(bool stats, bool all, bool query, bool ring)
 {
     if (ring) return all ? (Mega3Kernel)k_mega3<2, false, true, false, R16, true, DEC> : (Mega3Kernel)k_mega3<2, false, false, false, R16, true, DEC>;
@@ -1524,6 +1657,7 @@ Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, b
     if (stats) return r16 ? (Mega3Kernel)k_mega3<0, true, false, false, true> : (Mega3Kernel)k_mega3<0, true, false, false, false>;
     return r16 ? (Mega3Kernel)k_mega3<0, false, false, false, true> : (Mega3Kernel)k_mega3<0, false, false, false, false>;
 }
+#endif
 // rays per wave / stack levels in LDS of a launch's kernel
 uint32_t mega3_pool_p(bool dec, bool ring) { return dec ? (ring ? (uint32_t)Pool4LdsT<true, true>::P : (uint32_t)Pool4LdsT<true, false>::P) : (uint32_t)POOL3_P; }
 int mega3_lds_levels(bool dec, bool r16) { return dec ? (r16 ? Pool4LdsT<true, false>::LV : Pool4LdsT<false, false>::LV) : POOL_LV; }
@@ -1536,9 +1670,13 @@ bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t s
 {
     static const char* co = std::getenv("CRT_BBPROF_CO");
     // (the default instantiations: 16-bit stack entries, CRT_TRAVERSAL_EXACT, with the leaves decoupled or not)
+#ifdef CRT_ASM_ONLY_DEFAULT
+    const char* sym = nullptr;
+#else
     const char* sym = kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, true>    ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1EEEvNS_8MParams3E"
                       : kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, false> ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
                                                                                                   : nullptr;
+#endif
     if (!co || !*co || !sym) return false;
     enum { N_CNT = 4096, STRIDE = 128 };
     static hipModule_t mod = nullptr;

@@ -7,6 +7,11 @@ render one frame per Render object or the same frame again:
   * frames whose content differs from the frame before in the same Render (seed, camera, size): a stale line of the previous frame's
     radiance or path state would show, where a repeated frame hides it.
 Every frame against the CPU oracle, bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -54,3 +59,16 @@ def test_frames_that_differ_from_the_frame_before(name):
             assert np.array_equal(util.bits(r.mean_buffer), util.bits(omean)) and np.array_equal(rgb, orgb), (k, w, h, spp, seed, dx)
     finally:
         r.free()
+
+
+def test_200_first_frames_of_alternating_renders_of_equal_size():
+    """200 short-lived Render objects of equal size alternating between the two scenes (every fifth through the commit
+    ring), first frames only, every new device allocation pre-filled with 0xFF bytes, against the oracle -- in a child process, because
+    CRT_DEBUG_FILL is read when the library makes its first allocation."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CRT_DEBUG_FILL="255")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "first_frame_stress_driver.py"), "200"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["first_frames"] == 200 and res["debug_fill"] == "255"
+    assert res["bad_frames"] == [], res

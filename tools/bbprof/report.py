@@ -27,7 +27,7 @@ def phase_ranges():
     k0 = next(i for i, l in enumerate(lines) if "void k_mega3(const MParams3 M3)" in l) + 1
     marks = [("sched", r"^\s*for \(;;\) \{\s*$"), ("inner", r"auto inner_arm = "), ("leaf", r"auto leaf_arm = "), ("inner", r"auto inner_arm_dec = "), ("leaf", r"auto leaf_arm_dec = "),
              ("sched2", r"^\s*const bool plain = MODE == 1 \|\| n_exact == 0;"),
-             ("LA", r"if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"^\s*\} else \{\s*$"), ("end", r"^#undef PUSH3")]
+             ("LA", r"if \(act == PH3_LA\) \{"), ("LB", r"else if \(act == PH3_LB\) \{"), ("LC", r"if \(act != PH3_LA && act != PH3_LB\) \{"), ("end", r"^#undef PUSH3")]
     at, cur = [], k0
     for name, pat in marks:
         while not re.search(pat, lines[cur]):

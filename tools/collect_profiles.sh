@@ -23,7 +23,13 @@ groups=(
 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"
 "GRBM_GUI_ACTIVE GRBM_TA_BUSY"
 "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INST_CYCLES_VALU"
+"TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum"
+"TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum"
+"TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum"
 )
+# (round 5: the L2's fabric-side request counters by size -- FETCH_SIZE / WRITE_SIZE are derived from them with one assumed size; the
+# _32B forms count 32-byte units whatever the request's size, i.e. exact bytes.  "DRAM" = destined for the device's own memory, which
+# includes what the Infinity Cache in front of it answers: this rocprofv3 exposes no counter behind that cache, rocprofv3 --list-avail)
 for wl in c2 c3; do
   if [ $wl = c2 ]; then probe="--scene cornell-box --spp 512"; else probe="--scene veach-mis --spp 1024"; fi
   i=0

@@ -63,6 +63,12 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
             w["valu_class_costs"] = {c: list(cost) for c, cost in COST.items()}
     if v.get("TCC_HIT_sum") is not None and v.get("TCC_MISS_sum") is not None and (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]) > 0:
         w["tcc_miss_frac"] = round(v["TCC_MISS_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4)
+    if v.get("TCC_EA0_RDREQ_DRAM_32B_sum") is not None and v.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum") is not None:
+        # exact bytes on the L2's fabric side: 32-byte units of reads, writes and atomics bound for the device's own memory
+        w["fabric_read_bytes"] = 32.0 * v["TCC_EA0_RDREQ_DRAM_32B_sum"]
+        w["fabric_write_bytes"] = 32.0 * (v["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] + v.get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0))
+        if v.get("TCC_EA0_RDREQ_sum"):
+            w["fabric_read_bytes_per_request"] = round(w["fabric_read_bytes"] / v["TCC_EA0_RDREQ_sum"], 2)
     if v.get("SQ_LDS_BANK_CONFLICT") is not None and v.get("SQ_LDS_IDX_ACTIVE"):
         w["lds_conflict_frac"] = round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 4)
     res["workloads"][wl] = w

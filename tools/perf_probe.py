@@ -24,6 +24,6 @@ for i in range(a.reps):
     r.run_view(t.eye_pos, iv, fov, want_mean=False)
     dt = time.perf_counter() - t0
     s = r.stats
-    print(json.dumps({"wall_ms": round(dt * 1e3, 1), "total_ms": round(s["total_ms"], 1), "trace_ms": round(s["kernel_ms"], 1),
+    print(json.dumps({"wall_ms": round(dt * 1e3, 1), "total_ms": round(s["total_ms"], 1), "trace_ms": round(s["kernel_ms"], 3),
                       "logic_ms": round(s["logic_ms"], 1), "launches": s["kernel_launches"], "rays": s["rays"],
                       "Mrays/s": round(s["rays"] / s["total_ms"] / 1e3, 1), "env": {k: v for k, v in os.environ.items() if k.startswith("CRT_")}}))
