@@ -308,6 +308,22 @@ def main_rank(args):
         else:
             dist.init_process_group(backend="nccl", device_id=device)
 
+    # What the collective backend really spans (the first run on an 8-GPU node should prove RCCL saw 8 ranks on 8 devices): every rank
+    # adds a device-resident 1 through the process group, and the PCI bus ids of the ranks' devices are all-gathered over the same group.
+    collective_proof = None
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int32, device=(torch.device("cpu") if backend == "gloo" else device))
+        dist.all_reduce(ones)
+        try:
+            bus = torch.cuda.get_device_properties(device).pci_bus_id
+        except Exception:
+            bus = -1
+        mine = torch.tensor([int(bus), int(local_rank)], dtype=torch.int32, device=ones.device)
+        allb = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allb, mine)
+        collective_proof = {"backend": backend, "ranks_counted_by_all_reduce": int(ones.item()),
+                            "distinct_devices": len({(int(t[0]), int(t[1])) for t in allb})}
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -706,10 +722,14 @@ def main_rank(args):
             from PIL import Image
             Image.fromarray(img.cpu().numpy()).save(args.save_png)
         rccl_ranks = 0
+        rccl_evidence = None
         if multi:
-            rccl_ranks = int(mr.info["rccl_ranks"])
+            rccl_ranks = int(mr.info["rccl_ranks"])   # ncclCommCount of the communicator crt_multi_render gathers on (0: peer copies)
+            rccl_evidence = {"source": "ncclCommCount (crt_multi_info.rccl_ranks)", "fallback_reason": mr.info.get("fallback_reason") or None}
         elif world > 1 and backend == "nccl":
-            rccl_ranks = dist.get_world_size()
+            rccl_ranks = int(collective_proof["ranks_counted_by_all_reduce"])
+            rccl_evidence = dict(collective_proof, source="sum of a device tensor of ones all-reduced over the RCCL process group (torch exposes no ncclCommCount); "
+                                                         "distinct_devices = PCI bus ids all-gathered over the same group")
         line = {
             "metric": "Mrays/sec", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -733,7 +753,7 @@ def main_rank(args):
             "rays_definition": "calls of the reference's closest-hit query DeviceBVH::intersect (SURVEY 8(d)); counted by the kernel, "
                                "equal to the oracle's count",
             "collective": {"backend": ("rccl" if rccl_ranks else ("copy" if multi and n_gpus > 1 else (backend or "none"))),
-                           "rccl_ranks": rccl_ranks,
+                           "rccl_ranks": rccl_ranks, "rccl_evidence": rccl_evidence, "proof": collective_proof,
                            "launched_by": "torch.distributed.run" if (world > 1 and not os.environ.get("CRT_BENCH_SPAWNED")) else
                                           ("bench.py (self-started ranks)" if world > 1 else "single process")},
             "build_flags": B.built_flags() if not os.environ.get("CRT_LIB_PATH") else "unknown (CRT_LIB_PATH)",

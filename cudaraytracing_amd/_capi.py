@@ -81,10 +81,13 @@ class Stats(C.Structure):
 class MultiInfo(C.Structure):
     _fields_ = [("n_ranks", C.c_uint32), ("gather", C.c_uint32), ("rccl_ranks", C.c_uint32), ("rccl_version", C.c_int32),
                 ("render_ms", C.c_float), ("gather_ms", C.c_float), ("frame_ms", C.c_float), ("max_kernel_ms", C.c_float),
-                ("bytes_per_rank", C.c_uint64), ("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_untraced", C.c_uint64)]
+                ("bytes_per_rank", C.c_uint64), ("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_untraced", C.c_uint64),
+                ("fallback_reason", C.c_char * 160)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        d["fallback_reason"] = d["fallback_reason"].decode("utf-8", "replace")
+        return d
 
 
 class BvhBuildInfo(C.Structure):
@@ -116,7 +119,7 @@ TRI_DTYPE = np.dtype([("v1", "<f4", 3), ("v2", "<f4", 3), ("v3", "<f4", 3), ("no
 MAT_DTYPE = np.dtype([("kd", "<f4", 3), ("ke", "<f4", 3), ("ns", "<f4"), ("mode", "<i4"), ("has_emit", "<i4")])
 LIGHT_DTYPE = np.dtype([("first_tri", "<u4"), ("count", "<u4")])
 
-ABI_VERSION = 4  # include/crt.h: CRT_ABI_VERSION
+ABI_VERSION = 5  # include/crt.h: CRT_ABI_VERSION
 
 # every symbol include/crt.h declares
 EXPORTS = ["crt_strerror", "crt_last_error", "crt_abi_version", "crt_device_count", "crt_scene_create",

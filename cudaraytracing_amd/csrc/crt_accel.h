@@ -219,10 +219,18 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
     t[0].box = nodes[0].box[0]; t[0].box.grow(nodes[0].box[1]); t[0].area = t[0].box.half_area();
     int root = 0;
     auto is_leaf = [&](int x) { return t[x].child[0] < 0; };
-    auto refit_up = [&](int x) {
-        for (; x >= 0; x = t[x].parent) {
+    // (a box that comes out as it was leaves every ancestor as it was: the walk ends there -- most walks after a few levels instead of
+    // at the root, which is where the pass spent two thirds of its time; round 5)
+    auto same_box = [](const Box& a, const Box& b) {
+        return a.lo[0] == b.lo[0] && a.lo[1] == b.lo[1] && a.lo[2] == b.lo[2] && a.hi[0] == b.hi[0] && a.hi[1] == b.hi[1] && a.hi[2] == b.hi[2];
+    };
+    // (`stale`: the first node's stored box describes OTHER children -- the parent node that travels with a reinserted subtree -- and says
+    // nothing about its new ancestors)
+    auto refit_up = [&](int x, bool stale) {
+        for (; x >= 0; x = t[x].parent, stale = false) {
             Box b = t[t[x].child[0]].box;
             b.grow(t[t[x].child[1]].box);
+            if (!stale && same_box(b, t[x].box)) break;
             t[x].box = b;
             t[x].area = b.half_area();
         }
@@ -245,7 +253,7 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
             // take x (and its parent node P) out: the sibling moves up
             t[G].child[t[G].child[0] == P ? 0 : 1] = S;
             t[S].parent = G;
-            refit_up(G);
+            refit_up(G, false);
             // where does it cost least?  A move must pay: `orig` is what putting x back beside its old sibling costs, and a new place has
             // to beat it by the margin (default one half; CRT_SAH_OPT_MARGIN) -- reinsertions that gain next to nothing only stir up
             // overlap, and with the bound known beforehand the search ends near the root for the nodes that stay (most of them)
@@ -260,6 +268,7 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
                 for (int y = t[S].parent; y >= 0; y = t[y].parent) {
                     Box v = t[y].box;
                     v.grow(bx);
+                    if (same_box(v, t[y].box)) break; // (x lies inside y's box, hence inside every ancestor's: nothing more is added)
                     orig += v.half_area() - t[y].area;
                 }
                 best = orig * (1.0 - margin);
@@ -288,7 +297,7 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
             t[best_x].parent = P; t[x].parent = P;
             if (Q >= 0) t[Q].child[t[Q].child[0] == best_x ? 0 : 1] = P;
             else root = P;
-            refit_up(P);
+            refit_up(P, true);
         }
     }
     // back to the breadth-first array of inner nodes

@@ -579,8 +579,11 @@ crt_task load_task(const std::string& config_path, TaskObjs* all_objs)
 // reference: src/main.cu:122-145
 void load_task_scene(const crt_task& task, Scene& scene, const std::string& base_dir, const TaskObjs* all_objs)
 {
-    if (task.n_objs > 8 && (!all_objs || all_objs->size() != task.n_objs))
+    if (task.n_objs > 8 && !all_objs)
         throw Error(CRT_ERR_INVALID_ARG, "load_task_scene: a task of more than 8 OBJ files needs the list load_task returns");
+    // (a list is indexed up to n_objs below: one that belongs to another task -- or an empty one -- must not be read past its end)
+    if (all_objs && all_objs->size() != task.n_objs)
+        throw Error(CRT_ERR_INVALID_ARG, "load_task_scene: the OBJ list has " + std::to_string(all_objs->size()) + " entries, the task " + std::to_string(task.n_objs));
     auto resolve = [&](const char* p) {
         std::string s(p);
         if (!s.empty() && s[0] == '/') return s;

@@ -116,7 +116,11 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     const bool finite = ((sc.coord_max + max_o) * max_inv <= 0x1p126f) & finite3(nr.d.x, nr.d.y, nr.d.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
     // (MODE 0 / 2: a ray that is not RF_EXACT walks the 4-wide tree)
+#if CRT_WIDE != 4
+    const int ref = (MODE != 1 && finite && !force_exact) ? (LDS::DEC ? sc.rootw : sc.root4) : sc.root3_exact;
+#else
     const int ref = (MODE != 1 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
+#endif
     bool answered = false;
     float T = FLT_MAX;
     if (MODE != 1 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
@@ -194,7 +198,11 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
     const float4 la = gld(&pl.la[g]);
     const uint4 idv = load_path_id<RING>(P, g);
+#if CRT_X_NOVN
+    const float4 vn = gld(&sc.tri_nm[idv.w]); // (normal, material) of the vertex in the planes: from its triangle (the id plane's second word)
+#else
     const float4 vn = gld(&pl.vn[g]);
+#endif
     const float4 cc = gld(&pl.cc[g]); // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
     const int res_tri = __float_as_int(qb.w);
@@ -235,10 +243,10 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             const F3 pn = s.nrm;
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
             cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
-            gst(&pl.rec_a[pr].w, cos_prev);
+            gst_rec(&pl.rec_a[pr].w, cos_prev);
             if (__float_as_uint(pm1_old.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
                 const float ns = mat_row(tb, s.mat, 0).w;
-                const float4 pb = gld(&pl.rec_b[pr]); // direction that arrived at the previous vertex
+                const float4 pb = gld_rec(&pl.rec_b[pr]); // direction that arrived at the previous vertex
                 const float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
                 const F3 in = unit3(f3(pb.x, pb.y, pb.z));
                 const F3 out = sub3(in, scale3(pn, 2.f * dot3(in, pn)));
@@ -247,7 +255,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
                 const U4 rp = rng_draw(P.seed, s.pixel_index, s.k, s.depth - 1, RNG_PROBE, 0);
                 const F3 refd = unit3(sample_lobe(out, d_theta, d_phi, rng_uniform(rp.x), rng_uniform(rp.y)));
                 // the probe leaves from prev.pos (= this ray's origin); the bounce direction waits in rec_b[depth]
-                gst(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f));
+                gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f));
                 gst(&pl.vx[g], make_float4(pos.x, pos.y, pos.z, __int_as_float(res_tri)));
                 gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_PROBE << 8) | (s.q << 16))));
                 nr.o = s.ro; nr.d = unit3(refd); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = RF_PROBE;
@@ -275,12 +283,12 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
                 // shininess * (ke (.) kd) * cos * inv_pdf  (:311, eager)
                 const F3 kekd = mul3(f3(h2.x, h2.y, h2.z), f3(pm1.x, pm1.y, pm1.z));
                 const F3 temp = scale3(scale3(scalel3(shininess_coeff, kekd), ct), ip);
-                float4 a = gld(&pl.rec_a[pr]);
+                float4 a = gld_rec(&pl.rec_a[pr]);
                 a.x = a.x + temp.x; a.y = a.y + temp.y; a.z = a.z + temp.z;
-                gst(&pl.rec_a[pr], a);
+                gst_rec(&pl.rec_a[pr], a);
             }
         }
-        const float4 pb = gld(&pl.rec_b[(size_t)s.depth * pl.n + g]); // the bounce direction that found the current vertex
+        const float4 pb = gld_rec(&pl.rec_b[(size_t)s.depth * pl.n + g]); // the bounce direction that found the current vertex
         s.rd = f3(pb.x, pb.y, pb.z);
         do_enter = true;
     }
@@ -292,9 +300,13 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         }
         s.nrm = f3(gq.x, gq.y, gq.z);
         s.mat = __float_as_uint(gq.w);
-        gst(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
+        gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
         gst(&pl.vx[g], make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri)));
+#if CRT_X_NOVN
+        store_path_tri(P, g, s.vtri);
+#else
         gst(&pl.vn[g], make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat)));
+#endif
         if (__float_as_uint(m1_cur.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
             gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16))));
             return PH3_LC;
@@ -356,7 +368,7 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
         if (!shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w))) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
-    gst(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, 0.0f));
+    gst_rec(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, 0.0f));
     bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
     U4 rb;
     rb.x = rb.y = rb.z = rb.w = 0;
@@ -368,7 +380,11 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
         gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8))));
         return PH3_LC;
     }
+#if CRT_X_NOVN
+    const float4 vn = gld(&P.sc.tri_nm[idv.w]), vx = gld(&pl.vx[g]);
+#else
     const float4 vn = gld(&pl.vn[g]), vx = gld(&pl.vx[g]);
+#endif
     const F3 ndir = unit3(sample_hemisphere(f3(vn.x, vn.y, vn.z), rng_uniform(rb.y), rng_uniform(rb.z)));
     depth++;
     gst(&pl.la[g], make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8))));
@@ -412,7 +428,11 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
         if (stage == ST_HIT) deepest = (int)depth - 1; // the ray that looked for vertex `depth` missed (Render.cuh:210)
         else if ((st >> 16) & 1u) {
             emissive = true;
+#if CRT_X_NOVN
+            const float4 m2 = mat_row(tb, __float_as_uint(gld(&P.sc.tri_nm[idv.w]).w), 2);
+#else
             const float4 m2 = mat_row(tb, __float_as_uint(gld(&pl.vn[g]).w), 2);
+#endif
             ke = f3(m2.x, m2.y, m2.z);
         }
         const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
@@ -897,6 +917,145 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     return over;
 }
 
+#if CRT_WIDE != 4
+// ---- experiment builds (-DCRT_WIDE=6 / 8, round 5): the decoupled inner step at a node of CRT_WIDE children ----
+// Children 0..3 are a quad in the layout of a nodes4 node; children 4.. a second quad (CRT_WIDE 8) or a pair (CRT_WIDE 6: per axis one
+// float4 (lo c4, lo c5, hi c4, hi c5), the near / far halves picked by the load address as for the quads).  Everything else is
+// inner4_step_dec with CRT_WIDE in place of four: one accept mask per child, CRT_WIDE appends to the leaf queue, the nearest inner child
+// to the front by a tournament (CRT_WIDE - 1 exchanges), the others pushed.
+__device__ __forceinline__ void slab_pair_hits(const float2 nx, const float2 fx, const float2 ny, const float2 fy, const float2 nz, const float2 fz,
+                                               const F3 o, const F3 inv, float& e0, float& e1, unsigned long long& h0, unsigned long long& h1)
+{
+    // (scalar arithmetic: a subtraction and a multiplication issue in 2.5 cycles each, a packed one in 4.4 -- for one pair the packed form buys
+    // nothing, and the compiler built its broadcast operands through scratch memory)
+    const float nax = (nx.x - o.x) * inv.x, nay = (nx.y - o.x) * inv.x, nbx = (ny.x - o.y) * inv.y, nby = (ny.y - o.y) * inv.y, ncx = (nz.x - o.z) * inv.z, ncy = (nz.y - o.z) * inv.z;
+    const float fax = (fx.x - o.x) * inv.x, fay = (fx.y - o.x) * inv.x, fbx = (fy.x - o.y) * inv.y, fby = (fy.y - o.y) * inv.y, fcx = (fz.x - o.z) * inv.z, fcy = (fz.y - o.z) * inv.z;
+    e0 = fmax3(nax, nbx, ncx); e1 = fmax3(nay, nby, ncy);
+    const float x0 = fmin3(fax, fbx, fcx), x1 = fmin3(fay, fby, fcy);
+    h0 = __builtin_amdgcn_ballot_w64(e0 <= x0 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x0 >= 0);
+    h1 = __builtin_amdgcn_ballot_w64(e1 <= x1 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x1 >= 0);
+}
+template <bool STATS, class LDS, int CHECK = 0>
+__device__ __forceinline__ bool innerw_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 dir,
+                                                int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
+                                                uint32_t& n_leaf, const bool enable, const uint32_t cap_left = 0, bool* bailed = nullptr, bool* voided = nullptr)
+{
+    constexpr int W = CRT_WIDE;
+    constexpr uint32_t NODE_BYTES = W == 8 ? 256u : 192u;
+    const char* nb = (const char*)sc.nodesw;
+    const uint32_t noff = enable ? (uint32_t)ref * NODE_BYTES : sc.emptyw_off;
+    const uint32_t sx = (__float_as_uint(dir.x) >> 27) & 16u, sy = (__float_as_uint(dir.y) >> 27) & 16u, sz = (__float_as_uint(dir.z) >> 27) & 16u;
+    const uint32_t ox = noff + sx, oy = noff + sy, oz = noff + sz;
+    const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
+    const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
+    const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
+    const float4 rfa = *(const float4*)((nb + noff) + 112);
+    float t[W];
+    int r[W];
+    unsigned long long H[W];
+    const int top = stack_top_ahead(S, id, sp, LDS::LV);
+    F3 inv = inv3_exact(dir);
+    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z)); // (three scalars: packed into a vector the compiler extracts pairs of it through scratch memory)
+    const float inf = pinf();
+    slab_quad_hits(a0, a1, a2, b0, b1, b2, o, inv, t[0], t[1], t[2], t[3], H[0], H[1], H[2], H[3]);
+    r[0] = __float_as_int(rfa.x); r[1] = __float_as_int(rfa.y); r[2] = __float_as_int(rfa.z); r[3] = __float_as_int(rfa.w);
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+    // (the second half is fetched once the first has been consumed: fourteen loads in flight at once do not fit the registers of a wave
+    // that runs four to a SIMD -- the compiler then shuffles the ray's own values through scratch memory)
+    if constexpr (W == 8) {
+        const float4 c0 = *(const float4*)((nb + ox) + 128), c1 = *(const float4*)((nb + (ox ^ 16u)) + 128);
+        const float4 c2 = *(const float4*)((nb + oy) + 160), d0 = *(const float4*)((nb + (oy ^ 16u)) + 160);
+        const float4 d1 = *(const float4*)((nb + oz) + 192), d2 = *(const float4*)((nb + (oz ^ 16u)) + 192);
+        const float4 rfb = *(const float4*)((nb + noff) + 240);
+        slab_quad_hits(c0, c1, c2, d0, d1, d2, o, inv, t[4], t[5], t[6], t[7], H[4], H[5], H[6], H[7]);
+        r[4] = __float_as_int(rfb.x); r[5] = __float_as_int(rfb.y); r[6] = __float_as_int(rfb.z); r[7] = __float_as_int(rfb.w);
+        asm volatile("" : "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+    } else {
+        const uint32_t px = noff + (sx >> 1), py = noff + (sy >> 1), pz = noff + (sz >> 1); // + 8: the hi half of the row is the near one
+        const float2 p0 = *(const float2*)((nb + px) + 128), q0 = *(const float2*)((nb + (px ^ 8u)) + 128);
+        const float2 p1 = *(const float2*)((nb + py) + 144), q1 = *(const float2*)((nb + (py ^ 8u)) + 144);
+        const float2 p2 = *(const float2*)((nb + pz) + 160), q2 = *(const float2*)((nb + (pz ^ 8u)) + 160);
+        const float2 rfb = *(const float2*)((nb + noff) + 176);
+        slab_pair_hits(p0, q0, p1, q1, p2, q2, o, inv, t[4], t[5], H[4], H[5]);
+        r[4] = __float_as_int(rfb.x); r[5] = __float_as_int(rfb.y);
+        asm volatile("" : "+v"(t[4]), "+v"(t[5]));
+    }
+    uint32_t tail = lq_t + added;
+    unsigned long long m[W], ii[W];
+    uint32_t n_entries = 0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const unsigned long long N = __builtin_amdgcn_ballot_w64(r[i] < 0);
+        m[i] = H[i] & N; ii[i] = H[i] & ~N;
+        n_entries += (uint32_t)__popcll(m[i]);
+    }
+    unsigned long long void_mask = 0ull;
+    if (CHECK != 0) {
+        if (n_entries > cap_left) {
+            if (CHECK == 2) { *bailed = true; return false; }
+            // the lanes a W-th of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
+            const unsigned long long km = __builtin_amdgcn_ballot_w64((uint32_t)(threadIdx.x & 63) < cap_left / (uint32_t)W);
+#pragma unroll
+            for (int i = 0; i < W; i++) { m[i] &= km; ii[i] &= km; }
+            void_mask = ~km;
+        }
+    }
+    if (CHECK == 1) *voided = __builtin_amdgcn_inverse_ballot_w64(void_mask);
+    if (STATS && enable && !(CHECK == 1 && *voided)) tc.inner++;
+    n_leaf = 0;
+    unsigned long long many = 0ull;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        const bool l = __builtin_amdgcn_inverse_ballot_w64(m[i]);
+        leafq_push_all(S, l, m[i], ((uint32_t)r[i] & 0x7fffff00u) | id, tail);
+        n_leaf += l ? 1u : 0u;
+        many |= m[i];
+        t[i] = __builtin_amdgcn_inverse_ballot_w64(ii[i]) ? t[i] : inf;
+    }
+    added = tail - lq_t;
+    any_leaf = __builtin_amdgcn_inverse_ballot_w64(many);
+#define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
+    // the nearest inner child to the front: a tournament
+#pragma unroll
+    for (int s_ = 1; s_ < W; s_ *= 2)
+#pragma unroll
+        for (int i = 0; i + s_ < W; i += 2 * s_) CRT_CE(t[i], r[i], t[i + s_], r[i + s_])
+#undef CRT_CE
+    constexpr int LV = LDS::LV;
+    typedef typename LDS::stk_t stk_t;
+    bool c[W];
+    int lvl[W];
+    int run = sp;
+#pragma unroll
+    for (int k = W - 1; k >= 1; k--) {
+        c[k] = t[k] < inf;
+        lvl[k] = run;
+        if (c[k] & (run < LV)) S.stk[run][id] = (stk_t)r[k];
+        run += c[k] ? 1 : 0;
+    }
+    const int sp_new = run;
+    if (__builtin_amdgcn_ballot_w64((sp_new > sp) & (sp_new > LV))) {
+#pragma unroll
+        for (int k = W - 1; k >= 1; k--)
+            if (c[k] & (lvl[k] >= LV)) M.spill[(size_t)(lvl[k] - LV) * M.M.spill_stride + g] = r[k];
+    }
+    sp = sp_new;
+    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    const bool c0_ = t[0] < inf;
+    const bool pop = !c0_ & (sp > 0);
+    const bool over = !c0_ & (sp == 0);
+    ref = c0_ ? r[0] : top;
+    sp -= pop ? 1 : 0;
+    if (__builtin_amdgcn_ballot_w64(pop & (sp >= LV))) {
+        if (pop & (sp >= LV)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
+    }
+    return over;
+}
+#define inner_step_dec_x innerw_step_dec
+#else
+#define inner_step_dec_x inner4_step_dec
+#endif
+
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
 // visit order, no pruning) or, for the handful of FAST rays with non-finite operands, reference arithmetic on that topology
 // with ordering and pruning.  d = direction (the sign selects the near plane, DeviceBVH.cuh:101-119).
@@ -1234,10 +1393,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     // free, so the difference cannot be negative -- but a wrapped unsigned here would switch the overflow check off for good)
                     const uint32_t lq_used = (lq_t - lq_h) + (MAY_EXACT ? 64u : 0u);
                     const uint32_t lq_free = lq_used < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used : 0u;
-                    const bool done4 = inner4_step_dec<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
+                    const bool done4 = inner_step_dec_x<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
                                                                        lq_free, nullptr, &voided);
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
+#ifdef CRT_MERGE_BRANCHES
                     if (en && !voided) { ref = ref4; sp = sp4; done = done4; }
+#else
+                    {   // (selects, not a branch around three moves: the exec-mask save / restore of such a region costs more than it skips)
+                        const bool take4 = en & !voided;
+                        ref = take4 ? ref4 : ref; sp = take4 ? sp4 : sp; done = take4 ? done4 : done;
+                    }
+#endif
                     if (STATS && en && voided) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
@@ -1256,8 +1422,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                             bool bailed = false, any2 = false;
                             uint32_t n2 = 0;
                             int ref5 = ref, sp5 = sp;
-                            const bool done5 = inner4_step_dec<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
+                            const bool done5 = inner_step_dec_x<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
+#ifdef CRT_MERGE_BRANCHES
                             if (!bailed && en2) { ref = ref5; sp = sp5; done = done5; n_leaf += n2; any_leaf = any_leaf | any2; }
+#else
+                            {
+                                const bool take5 = en2 & !bailed;
+                                ref = take5 ? ref5 : ref; sp = take5 ? sp5 : sp; done = take5 ? done5 : done;
+                                n_leaf += take5 ? n2 : 0u; any_leaf = any_leaf | (take5 & any2);
+                            }
+#endif
                             if (STATS && bailed && en2) dg_ov[1]++;
                         }
                     }
@@ -1326,6 +1500,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float bt = 0.0f;
                 int bi = 0;
                 int left = 1;
+#ifdef CRT_ONE_RECORD /* experiment, not taken (round 5): C2 78.55 / 78.33 -> 78.66 / 78.92 ms, veach-mis spp 256 77.87 / 77.93 -> 78.04 / 78.08 -- eleven
+                         instructions fewer per leaf step, and the second copy of the pair test in the kernel costs what they save */
+                // (no leaf of the scene has more than two triangles -- bvh_thresh_n <= 2, both shipped configs: a leaf IS one record, and the
+                // step runs without the loop over a leaf's records, its exec-mask bookkeeping and the running best; a wave-uniform branch)
+                if (sc.one_record) {
+                    const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
+                    const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
+                    const int it = __float_as_int(g4.z);
+                    const bool two = __float_as_int(g4.w) > 1;
+                    bool a0, a1;
+                    float t0, t1;
+                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
+                    if (STATS) { tc.tests += two ? 2u : 1u; }
+                    const bool b0 = a0 & (Tl - t0 > CRT_EPSILON);
+                    const bool b1 = a1 & two & (Tl - t1 > CRT_EPSILON);
+                    const bool s1 = b1 & (!b0 | (t1 < t0));
+                    bt = s1 ? t1 : t0; bi = s1 ? it + 1 : it; have = b0 | b1;
+                    left = 0;
+                }
+#endif
                 for (int k = 0; left > 0; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
                     const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
                     const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -174,6 +175,7 @@ struct crt_multi {
     float* mean = nullptr;     // rank 0: row-major mean
     size_t frame_cap = 0, mean_cap = 0;
     bool last_had_mean = false; // the last crt_multi_render wrote `mean`
+    std::string fallback_reason; // CRT_GATHER_AUTO only: why RCCL was not used although the devices are distinct (empty: no fallback happened)
 };
 
 namespace {
@@ -223,6 +225,7 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
         for (uint32_t b = 0; b < a; b++) distinct = distinct && devices[a] != devices[b];
     }
     if (gather == CRT_GATHER_RCCL && !distinct) return mfail(CRT_ERR_INVALID_ARG, "crt_multi_create: RCCL needs one rank per device (duplicate device index)");
+    const uint32_t requested = gather;
     if (gather == CRT_GATHER_AUTO) gather = (distinct && n_devices > 1) ? CRT_GATHER_RCCL : CRT_GATHER_COPY;
     DeviceGuard guard;
     crt_multi* m = nullptr;
@@ -239,6 +242,44 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
             MHIP(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
             MHIP(hipEventCreateWithFlags(&rk.done, hipEventDisableTiming));
         }
+        // CRT_GATHER_AUTO prefers RCCL but does not depend on it: if the library cannot be bound or the communicator cannot be made (a
+        // node whose fabric RCCL refuses, a container without the IPC mode it needs), the frame is gathered by peer copies instead and
+        // crt_multi_info::fallback_reason says why.  An explicit CRT_GATHER_RCCL fails loudly, as before.
+        const bool auto_mode = requested == CRT_GATHER_AUTO;
+        if (gather == CRT_GATHER_RCCL) {
+            std::string why;
+            Rccl& R = rccl();
+            if (!R.ok) why = R.error;
+            else {
+                std::vector<ncclComm_t> comms(n_devices, nullptr);
+                std::vector<int> devs(devices, devices + n_devices);
+                ncclResult_t rv = R.GetVersion(&m->rccl_version);
+                if (rv == ncclSuccess) rv = R.CommInitAll(comms.data(), (int)n_devices, devs.data());
+                if (rv == ncclSuccess) {
+                    for (uint32_t r = 0; r < n_devices; r++) m->ranks[r].comm = comms[r];
+                    rv = R.CommCount(comms[0], &m->rccl_ranks);
+                }
+                if (rv != ncclSuccess) {
+                    why = std::string("ncclCommInitAll / ncclCommCount: ") + R.GetErrorString(rv);
+                    for (uint32_t r = 0; r < n_devices; r++) {
+                        if (m->ranks[r].comm) { (void)hipSetDevice(m->ranks[r].device); (void)R.CommDestroy(m->ranks[r].comm); m->ranks[r].comm = nullptr; }
+                    }
+                    (void)hipGetLastError();
+                } else if (m->rccl_ranks != (int)n_devices) {
+                    why = "ncclCommCount reports " + std::to_string(m->rccl_ranks) + " ranks for " + std::to_string(n_devices) + " devices";
+                }
+            }
+            if (!why.empty()) {
+                if (!auto_mode) { destroy(m); return mfail(R.ok ? CRT_ERR_HIP : CRT_ERR_UNSUPPORTED, "crt_multi_create: " + why); }
+                for (uint32_t r = 0; r < n_devices; r++) {
+                    if (m->ranks[r].comm) { (void)hipSetDevice(m->ranks[r].device); (void)R.CommDestroy(m->ranks[r].comm); m->ranks[r].comm = nullptr; }
+                }
+                m->fallback_reason = why;
+                m->rccl_ranks = 0;
+                gather = CRT_GATHER_COPY;
+                m->gather = gather;
+            }
+        }
         if (gather == CRT_GATHER_COPY && distinct && n_devices > 1) {
             // rank 0 receives peer writes
             for (uint32_t r = 1; r < n_devices; r++) {
@@ -251,16 +292,6 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
                     (void)hipGetLastError();
                 }
             }
-        }
-        if (gather == CRT_GATHER_RCCL) {
-            Rccl& R = rccl();
-            if (!R.ok) { std::string e = R.error; destroy(m); return mfail(CRT_ERR_UNSUPPORTED, "crt_multi_create: " + e); }
-            MNCCL(R.GetVersion(&m->rccl_version));
-            std::vector<ncclComm_t> comms(n_devices);
-            std::vector<int> devs(devices, devices + n_devices);
-            MNCCL(R.CommInitAll(comms.data(), (int)n_devices, devs.data()));
-            for (uint32_t r = 0; r < n_devices; r++) m->ranks[r].comm = comms[r];
-            MNCCL(R.CommCount(comms[0], &m->rccl_ranks));
         }
         *out = m;
         return CRT_OK;
@@ -396,6 +427,7 @@ int crt_multi_render(crt_multi* m, const crt_camera* cam, const crt_params* prm,
             info->gather_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
             info->frame_ms = std::chrono::duration<float, std::milli>(t2 - t0).count();
             info->bytes_per_rank = stride;
+            std::snprintf(info->fallback_reason, sizeof(info->fallback_reason), "%s", m->fallback_reason.c_str());
             for (uint32_t r = 0; r < world; r++) {
                 info->rays += st[r].rays; info->paths += st[r].paths; info->rays_untraced += st[r].rays_untraced;
                 info->max_kernel_ms = std::max(info->max_kernel_ms, st[r].kernel_ms);

@@ -138,6 +138,18 @@ __device__ __forceinline__ uint32_t gld(const uint32_t* p) { return *(const CRT_
 __device__ __forceinline__ void gst(float4* p, const float4 v) { crt_f4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(CRT_GAS crt_f4v_*)p = t; }
 __device__ __forceinline__ void gst(uint4* p, const uint4 v) { crt_u4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(CRT_GAS crt_u4v_*)p = t; }
 __device__ __forceinline__ void gst(float* p, const float v) { *(CRT_GAS float*)p = v; }
+// The vertex records (rec_a / rec_b): written when a vertex is entered, read once when the path ends, a few bounces later -- far apart
+// compared with the path-state planes, which one phase writes and the next reads within microseconds.  -DCRT_NT_RECORDS streams them past
+// the L2 (nt) so that they do not push the planes and the scene out of it (experiment, round 5).
+#ifdef CRT_NT_RECORDS
+__device__ __forceinline__ float4 gld_rec(const float4* p) { const crt_f4v_ v = __builtin_nontemporal_load((const CRT_GAS crt_f4v_*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void gst_rec(float4* p, const float4 v) { crt_f4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, (CRT_GAS crt_f4v_*)p); }
+__device__ __forceinline__ void gst_rec(float* p, const float v) { __builtin_nontemporal_store(v, (CRT_GAS float*)p); }
+#else
+__device__ __forceinline__ float4 gld_rec(const float4* p) { return gld(p); }
+__device__ __forceinline__ void gst_rec(float4* p, const float4 v) { gst(p, v); }
+__device__ __forceinline__ void gst_rec(float* p, const float v) { gst(p, v); }
+#endif
 
 // Takes the next work item for every lane that is active here with ONE atomic per wave and
 // shard (ballot of the active lanes, the first one adds their count, prefix rank per lane).
@@ -406,6 +418,36 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
 // needed (two multiply-shift divisions and the tile arithmetic).  Against keeping (pixel, sample, item) as 16 B, measured on C2 with
 // one --pmc pass per counter: memory-side traffic 431.7 -> 382.7 GB per launch, L2 miss rate 0.495 -> 0.467, vector instructions
 // + 1.2 %, frame 96.7 -> 95.5 ms (profiles/r03_traffic_id_plane.txt).  (The wavefront pipeline keeps the 16-byte entries.)
+// CRT_X_NOVN (round 5; 0 = the round-4 layout): k_mega3 keeps no `vn` plane (normal, material of the current vertex:
+// 16 B read in every LA and LB visit, written at every vertex) -- both are a function of the vertex's triangle, which travels in the second
+// word of an 8-byte id plane, and come from the L2-resident 16 B / triangle table tri_nm, one dependent load later.  Measured (C2, one
+// box): L2 <-> fabric traffic 348.6 -> 320.0 GB per frame (-8.2 %), L2 miss rate 0.475 -> 0.449, frame 78.0 -> 77.2 ms; veach-mis spp 256
+// 77.9 -> 77.5 ms.  (The wavefront pipeline keeps its vn plane.)
+#ifndef CRT_X_NOVN
+#define CRT_X_NOVN 1
+#endif
+#if CRT_X_NOVN
+template <bool RING = false>
+__device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
+{
+    typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
+    const u2v_ w = *(const CRT_GAS u2v_*)((const uint2*)P.pool.id + g);
+    uint32_t pixel_index, k, pi, pj;
+    bool valid;
+    decode_item<RING>(P, w.x, pixel_index, k, valid, pi, pj);
+    return make_uint4(pixel_index, k, w.x, w.y);
+}
+__device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t item)
+{
+    typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
+    u2v_ w; w.x = item; w.y = 0u; // (triangle 0: a valid row of tri_nm for the speculative load of a path's first visit)
+    *(CRT_GAS u2v_*)((uint2*)P.pool.id + g) = w;
+}
+__device__ __forceinline__ void store_path_tri(const LParams& P, const uint32_t g, const uint32_t tri)
+{
+    *(CRT_GAS uint32_t*)((uint32_t*)((uint2*)P.pool.id + g) + 1) = tri;
+}
+#else
 template <bool RING = false>
 __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
 {
@@ -419,6 +461,7 @@ __device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g
 {
     *(CRT_GAS uint32_t*)((uint32_t*)P.pool.id + g) = item;
 }
+#endif
 
 // Backward recursion over the vertex records, deepest first: Render.cuh:238-326.
 template <bool LDS_TABLES>
@@ -431,7 +474,7 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
     if (emissive) {
         L = deepest == 0 ? add3(f3(0.0f, 0.0f, 0.0f), ke) : f3(0.0f, 0.0f, 0.0f); // :249-255, :323
     } else {
-        float4 a = gld(&pl.rec_a[(size_t)deepest * pl.n + slot]);
+        float4 a = gld_rec(&pl.rec_a[(size_t)deepest * pl.n + slot]);
         L = add3(f3(0.0f, 0.0f, 0.0f), f3(a.x, a.y, a.z)); // final hit: direct light only (:316-319)
     }
     // The recursion is a serial chain, but its loads are not: the records (and material rows) of CRT_FINISH_PF vertices are
@@ -444,8 +487,8 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
 #pragma unroll
         for (int j = 0; j < CRT_FINISH_PF; j++) {
             const int vj = v - j > 0 ? v - j : 0;
-            a[j] = gld(&pl.rec_a[(size_t)vj * pl.n + slot]);
-            mat[j] = __float_as_uint(gld(&pl.rec_b[(size_t)vj * pl.n + slot]).w);
+            a[j] = gld_rec(&pl.rec_a[(size_t)vj * pl.n + slot]);
+            mat[j] = __float_as_uint(gld_rec(&pl.rec_b[(size_t)vj * pl.n + slot]).w);
         }
 #pragma unroll
         for (int j = 0; j < CRT_FINISH_PF; j++) fm[j] = mat_row(tb, mat[j], 0);

@@ -28,7 +28,7 @@ extern "C" {
  *    argument carries flag bits (CRT_INTERSECT_RAW_DIRECTIONS 0x100, _FORCE_EXACT 0x200, _VISIBILITY 0x400), progressive /
  *    preview / multi-device / accel-info entry points and structs added.  A client built against version 2 must be rebuilt:
  *    check crt_abi_version() == CRT_ABI_VERSION at load time. */
-#define CRT_ABI_VERSION 4
+#define CRT_ABI_VERSION 5
 
 typedef enum {
     CRT_OK = 0,
@@ -278,6 +278,8 @@ typedef struct {
     float max_kernel_ms;     /* largest crt_stats.kernel_ms over the ranks */
     uint64_t bytes_per_rank; /* size of one rank's block in the exchange */
     uint64_t rays, paths, rays_untraced; /* sums over the ranks */
+    char fallback_reason[160]; /* (ABI 5) CRT_GATHER_AUTO only: why the gather runs on peer copies although the devices are distinct -- librccl.so.1 not
+                                  found, ncclCommInitAll refused ...; empty when no fallback happened.  An explicit CRT_GATHER_RCCL fails instead. */
 } crt_multi_info;
 /* gather: CRT_GATHER_*.  Uploads the scene to every device (crt_scene_create per rank). */
 int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_devices, uint32_t gather, crt_multi** out);
@@ -358,7 +360,9 @@ int crt_inverse_view(const float eye[3], const float lookat[3], const float up[3
 
 /* Task / config.json (src/main.cu:40-90) */
 typedef struct {
-    uint32_t n_objs;           /* entries of OBJ_paths in the file -- any number, as src/main.cu:74-78 loops over them */
+    uint32_t n_objs;           /* entries of OBJ_paths in the file -- any number, as src/main.cu:74-78 loops over them.  The two arrays of this struct
+                                  hold the first 8 only: a client that walks obj_path[i] / mtl_dir[i] must stop at min(n_objs, 8) and take the rest
+                                  from crt_task_obj */
     char obj_path[8][512];     /* the first eight; crt_task_obj() returns any of them */
     char mtl_dir[8][512];
     float lookat[3], up[3], eye_pos[3];

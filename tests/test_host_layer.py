@@ -143,7 +143,7 @@ def test_library_exports_every_symbol_the_header_declares():
     lib = capi.lib()
     for name in declared:
         getattr(lib, name)
-    assert lib.crt_abi_version() == capi.ABI_VERSION == 4
+    assert lib.crt_abi_version() == capi.ABI_VERSION == 5
     assert lib.crt_strerror(-4).decode() == "unsupported"
 
 

@@ -139,6 +139,46 @@ def test_bench_started_plainly_starts_its_own_ranks(single, tmp_path):
     assert line["fast_vs_reference"]["pixels_differ_f32_bits"] == 0 and line["fast_vs_reference"]["rays_equal"]
 
 
+def test_bench_c4_resolution_on_four_self_started_ranks(single, tmp_path):
+    """the N > 1 line at C4's resolution (3840 x 2160, spp 2) with self-started ranks sharing the one GPU and gathering over
+    gloo -- FOUR of them: the box allows six processes on its card and the test runner is one (eight ranks in ONE process:
+    test_ranks_on_one_device_...[cornell-box-64-40-8] and --engine multi).  The gathered PNG must be the one-device frame, the line must carry
+    `per_rank` and say what its collective really spanned."""
+    from PIL import Image
+    png = str(tmp_path / "c4.png")
+    line = _bench(["--gpus", "4", "--workload", "c4", "--spp", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-c3", "--no-large-scene",
+                   "--save-png", png], {"CRT_BENCH_ONE_DEVICE": "1"})
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["collective"]["launched_by"].startswith("bench.py")
+    ev = line["collective"]["rccl_evidence"]
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["rccl_ranks"] == 0 and ev is None
+    assert line["collective"]["proof"]["ranks_counted_by_all_reduce"] == 4  # (one device here: distinct_devices counts (bus id, local rank) pairs)
+    pr = line["per_rank"]
+    assert 0 < pr["kernel_ms_min"] <= pr["kernel_ms_max"] and "non_kernel_ms_per_step" in pr
+    eye, iv, fov = util.camera("cornell-box")
+    one = single["cornell-box"]
+    one.set_spp(2)
+    one.traversal = crt.TRAVERSAL_EXACT
+    rgb = one.run_view(eye, iv, fov, width=3840, height=2160)
+    assert line["rays_per_frame"] == one.stats["rays"]
+    assert np.array_equal(np.asarray(Image.open(png)), rgb)
+
+
+def test_auto_gather_records_why_it_fell_back(single, monkeypatch):
+    """CRT_GATHER_AUTO never fails a frame because of RCCL: distinct devices whose communicator cannot be made render by peer copies and
+    crt_multi_info.fallback_reason says why (ABI 5).  On this one-GPU box AUTO with one device is a one-rank RCCL communicator (no fallback:
+    the reason is empty and ncclCommCount is 1), and with a repeated device it is peer copies by rule (no attempt, no reason)."""
+    eye, iv, fov = util.camera("cornell-box")
+    for devices, want_gather, want_ranks in (([0], None, None), ([0, 0], crt.GATHER_COPY, 0)):
+        m = _multi("cornell-box", devices, crt.GATHER_AUTO, 2)
+        try:
+            m.run_view(eye, iv, fov, width=64, height=40)
+            assert m.info["fallback_reason"] == ""
+            if want_gather is not None:
+                assert m.info["gather"] == want_gather and m.info["rccl_ranks"] == want_ranks
+        finally:
+            m.free()
+
+
 def test_bench_multi_engine_one_process(single):
     """`--engine multi`: one process, crt_multi_render; two ranks on the one GPU (peer copies), one rank over RCCL."""
     line = _bench(["--gpus", "2", "--engine", "multi", "--steps", "2", "--warmup", "1", "--spp", "4", "--width", "200", "--height", "152",

@@ -1,0 +1,56 @@
+// tools/sah_opt_bench.cpp -- host-side timing of the tree set-up of crt_scene_create on a scene file, without a GPU: the binned SAH build over
+// the reference's leaves (crt_accel.h: build_sah -- on a GPU box the device builder does this part) and the insertion-based optimisation pass
+// (optimize_sah), which is host code on every box and the larger part of `scene_setup.sah_tree.ms`.
+// build: g++ -O2 -std=c++17 -Iinclude -Icudaraytracing_amd/csrc tools/sah_opt_bench.cpp -Lcudaraytracing_amd/lib -lcrt -Wl,-rpath,$PWD/cudaraytracing_amd/lib -o /tmp/sah_opt_bench
+// usage: /tmp/sah_opt_bench scenes/cornell-box/config.json [reps]
+#include "crt.h"
+#include "crt_accel.h"
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+int main(int argc, char** argv)
+{
+    const char* cfg = argc > 1 ? argv[1] : "scenes/cornell-box/config.json";
+    const int reps = argc > 2 ? std::atoi(argv[2]) : 5;
+    crt_task task;
+    if (crt_task_load(cfg, &task) != 0) { std::printf("task: %s\n", crt_last_error()); return 1; }
+    crt_host_scene* hs = nullptr;
+    if (crt_host_scene_create(task.width, task.height, &hs) != 0) return 1;
+    for (uint32_t i = 0; i < task.n_objs && i < 8; i++)
+        if (crt_host_scene_add_obj(hs, task.obj_path[i], task.mtl_dir[i]) != 0) { std::printf("load: %s\n", crt_last_error()); return 1; }
+    if (crt_host_scene_set_bvh(hs, task.bvh_thresh_n) != 0) { std::printf("bvh: %s\n", crt_last_error()); return 1; }
+    crt_scene_desc d;
+    if (crt_host_scene_desc(hs, &d) != 0) return 1;
+    std::vector<crtaccel::Prim> prims0;
+    for (uint32_t i = 0; i < d.n_nodes; i++) {
+        if (!(d.nodes[i].lc < 0 && d.nodes[i].rc < 0)) continue;
+        crtaccel::Prim p;
+        for (int a = 0; a < 3; a++) { p.box.lo[a] = d.nodes[i].aa[a]; p.box.hi[a] = d.nodes[i].bb[a]; }
+        p.ref = ~(int32_t)i;
+        prims0.push_back(p);
+    }
+    using clk = std::chrono::steady_clock;
+    double best_build = 1e9, best_opt = 1e9;
+    size_t n_nodes = 0;
+    int depth = 0;
+    for (int r = 0; r < reps; r++) {
+        std::vector<crtaccel::Prim> prims = prims0;
+        std::vector<crtaccel::Node> nodes;
+        int32_t root = 0;
+        const auto t0 = clk::now();
+        crtaccel::build_sah(prims, nodes, root);
+        const auto t1 = clk::now();
+        depth = crtaccel::optimize_sah(nodes, 1);
+        const auto t2 = clk::now();
+        best_build = std::min(best_build, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        best_opt = std::min(best_opt, std::chrono::duration<double, std::milli>(t2 - t1).count());
+        n_nodes = nodes.size();
+        double area = 0;
+        for (const auto& n : nodes) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); area += b.half_area(); }
+        if (r == 0) std::printf("{\"leaves\": %zu, \"nodes\": %zu, \"depth\": %d, \"summed_area\": %.6e}\n", prims0.size(), n_nodes, depth, area);
+    }
+    std::printf("{\"host_build_sah_ms\": %.2f, \"optimize_sah_ms\": %.2f}\n", best_build, best_opt);
+    return 0;
+}

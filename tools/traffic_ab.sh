@@ -6,7 +6,8 @@ set -o pipefail
 tag=$1; shift
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
-groups=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU")
+groups=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"
+        "TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum TCC_EA0_RDREQ_sum")
 for lib in "$@"; do
   name=$(basename $lib .so)
   export CRT_LIB_PATH=$PWD/$lib
@@ -25,8 +26,11 @@ d = json.load(open(sys.argv[2]))
 k = next(v for n, v in d.items() if n.startswith("k_mega3"))
 ms = min(json.loads(l)["trace_ms"] for l in open(sys.argv[3]) if l.startswith("{"))
 traffic = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-print("%-22s %.2f ms  traffic %.1f GB (fetch %.1f x2 + write %.1f)  TCC miss %.3f  SQ_WAIT_ANY %.3f  VALU %.3g  lanes %.3f" % (
-    sys.argv[1], ms, traffic / 1e9, k["FETCH_SIZE"] * 1024 / 1e9, k["WRITE_SIZE"] * 1024 / 1e9, k["TCC_MISS_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]),
+exact_r = 32.0 * k.get("TCC_EA0_RDREQ_DRAM_32B_sum", 0.0)
+exact_w = 32.0 * (k.get("TCC_EA0_WRREQ_WRITE_DRAM_32B_sum", 0.0) + k.get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0))
+print("%-22s %.2f ms  traffic %.1f GB (fetch %.1f x2 + write %.1f)  exact 32-B units: read %.1f + write %.1f = %.1f GB (%.1f B per read request)  TCC miss %.3f  SQ_WAIT_ANY %.3f  VALU %.3g  lanes %.3f" % (
+    sys.argv[1], ms, traffic / 1e9, k["FETCH_SIZE"] * 1024 / 1e9, k["WRITE_SIZE"] * 1024 / 1e9, exact_r / 1e9, exact_w / 1e9, (exact_r + exact_w) / 1e9,
+    exact_r / max(1.0, k.get("TCC_EA0_RDREQ_sum", 0.0)), k["TCC_MISS_sum"] / (k["TCC_HIT_sum"] + k["TCC_MISS_sum"]),
     k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"], k["SQ_INSTS_VALU"], k["SQ_THREAD_CYCLES_VALU"] / k["SQ_ACTIVE_INST_VALU"] / 64))
 PY
   rm -rf $out
