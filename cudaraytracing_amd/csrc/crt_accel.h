@@ -29,6 +29,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <vector>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 namespace crtaccel {
 
@@ -187,7 +192,7 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
 // changes is the number of nodes and leaves a ray meets (one pass, moves that save at least half: cornell-box stand-in 5.04 -> 4.31
 // inner and 3.93 -> 3.68 leaf visits per ray, frame - 5.4 %; veach-mis - 1.7 %; the 102 412-triangle variant - 3.9 %).
 // Returns the new depth; nodes come back in breadth-first order, root = 0.
-inline int optimize_sah(std::vector<Node>& nodes, int passes)
+inline int optimize_sah_serial(std::vector<Node>& nodes, int passes)
 {
     const int A = (int)nodes.size();
     if (A < 3 || passes <= 0) {
@@ -316,6 +321,248 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes)
             const int c = t[order[q]].child[s];
             out[q].box[s] = t[c].box;
             out[q].child[s] = is_leaf(c) ? t[c].leaf_ref : index[c];
+        }
+    nodes.swap(out);
+    return md;
+}
+
+// The pass as crt_scene_create runs it (round 5): the same moves found SPECULATIVELY on several threads.  Of the ~49 000
+// nodes of the stand-in's tree 300 move; the time goes into the searches that end where they began.  A search never changes the tree: it
+// works on the tree as it is, with the node's removal emulated (the boxes along its root path shrunk in a thread-local overlay), so the
+// searches of a block of nodes run in parallel on a frozen tree.  The block is then applied in order: a node that stays only has its parent's
+// children put in the order (sibling, node) the serial pass leaves them in -- no box changes --; a node that moves is taken out and put in for
+// real, every node whose box or links change is stamped, and a later node of the block whose search READ a stamped node is searched again on
+// the tree as it then is.  Each result is therefore what a serial execution of this same algorithm produces: the output does not depend on
+// the number of threads or on timing.  (Against optimize_sah_serial the search pushes a node's children in the order of their ids instead of
+// their child slots, so that the sibling order the pass itself normalises cannot steer ties: the two forms may resolve exact ties between
+// equally good positions differently -- any tree over the reference's leaves renders the same frame.)
+inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
+{
+    const int A = (int)nodes.size();
+    if (A < 3 || passes <= 0) return optimize_sah_serial(nodes, passes);
+    if (n_threads <= 0) {
+        n_threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e_ = std::getenv("CRT_SAH_OPT_THREADS")) n_threads = std::max(1, std::atoi(e_));
+        if (n_threads == 1) return optimize_sah_serial(nodes, passes); // (one thread: the serial form does without the read sets and the overlay)
+    }
+    struct N { Box box; int parent, child[2]; int32_t leaf_ref; double area; };
+    std::vector<N> t((size_t)2 * A + 1);
+    int n_all = A;
+    for (int q = 0; q < A; q++) { t[q].parent = -1; t[q].leaf_ref = 0; }
+    for (int q = 0; q < A; q++)
+        for (int s = 0; s < 2; s++) {
+            const int32_t c = nodes[q].child[s];
+            int id;
+            if (c >= 0) id = c;
+            else { id = n_all++; t[id].child[0] = t[id].child[1] = -1; t[id].leaf_ref = c; }
+            t[q].child[s] = id;
+            t[id].parent = q;
+            t[id].box = nodes[q].box[s];
+            t[id].area = t[id].box.half_area();
+        }
+    t[0].box = nodes[0].box[0]; t[0].box.grow(nodes[0].box[1]); t[0].area = t[0].box.half_area();
+    int root = 0;
+    auto is_leaf = [&](int x) { return t[x].child[0] < 0; };
+    auto same_box = [](const Box& a, const Box& b) {
+        return a.lo[0] == b.lo[0] && a.lo[1] == b.lo[1] && a.lo[2] == b.lo[2] && a.hi[0] == b.hi[0] && a.hi[1] == b.hi[1] && a.hi[2] == b.hi[2];
+    };
+    double margin = 0.5;
+    if (const char* e_ = std::getenv("CRT_SAH_OPT_MARGIN")) margin = std::atof(e_);
+    std::vector<int> stamp((size_t)n_all, -1); // block in which a node's box or links last changed
+    struct Cand { double ind; int x; };
+    struct alignas(64) Work { // per thread (cache lines of its own: the vectors' headers are written at every push)
+        std::vector<Cand> heap;
+        std::vector<int> pidx;      // node -> index on the emulated root path, or -1
+        std::vector<int> path;      // the path nodes G .. root
+        std::vector<Box> sbox;      // their boxes with x taken out
+        std::vector<double> sarea;
+    };
+    struct alignas(64) Spec { int best_x; std::vector<int> read; }; // (a cache line each: neighbours are written by different threads)
+    // the search for node x on the tree as it is, x's removal emulated; `read` collects every node whose box or links it looked at
+    auto search = [&](int x, Work& w, Spec& out) {
+        out.read.clear();
+        const int P = t[x].parent;
+        out.best_x = -1;
+        out.read.push_back(x);
+        if (P < 0 || P == root) return;
+        const int S = t[P].child[0] == x ? t[P].child[1] : t[P].child[0];
+        const int G = t[P].parent;
+        out.read.push_back(P); out.read.push_back(S); out.read.push_back(G);
+        // the root path without x: boxes shrink until one comes out as it was
+        w.path.clear(); w.sbox.clear(); w.sarea.clear();
+        {
+            Box cur = t[S].box;
+            int below = P;
+            for (int y = G; y >= 0; below = y, y = t[y].parent) {
+                const int other = t[y].child[0] == below ? t[y].child[1] : t[y].child[0];
+                out.read.push_back(y); out.read.push_back(other);
+                Box b = cur;
+                b.grow(t[other].box);
+                if (y != G && same_box(b, t[y].box)) break; // (from here up nothing changes; G itself is always on the path: its children differ)
+                w.pidx[y] = (int)w.path.size();
+                w.path.push_back(y); w.sbox.push_back(b); w.sarea.push_back(b.half_area());
+                cur = b;
+            }
+        }
+        auto box_of = [&](int c) -> const Box& { return w.pidx[c] >= 0 ? w.sbox[(size_t)w.pidx[c]] : t[c].box; };
+        auto area_of = [&](int c) { return w.pidx[c] >= 0 ? w.sarea[(size_t)w.pidx[c]] : t[c].area; };
+        const Box bx = t[x].box;
+        const double ax = t[x].area;
+        double best = DBL_MAX;
+        int best_x = S;
+        if (margin > 0.0) {
+            Box u = t[S].box;
+            u.grow(bx);
+            double orig = u.half_area();
+            for (int y = G; y >= 0; y = t[y].parent) {
+                out.read.push_back(y);
+                Box v = box_of(y);
+                v.grow(bx);
+                if (same_box(v, box_of(y))) break;
+                orig += v.half_area() - area_of(y);
+            }
+            best = orig * (1.0 - margin);
+        }
+        auto cmp = [](const Cand& a, const Cand& b) { return a.ind != b.ind ? a.ind > b.ind : a.x > b.x; };
+        w.heap.clear();
+        w.heap.push_back(Cand{0.0, root});
+        while (!w.heap.empty()) {
+            std::pop_heap(w.heap.begin(), w.heap.end(), cmp);
+            const Cand c = w.heap.back();
+            w.heap.pop_back();
+            if (c.ind + ax >= best) break;
+            out.read.push_back(c.x);
+            Box u = box_of(c.x);
+            u.grow(bx);
+            const double direct = u.half_area();
+            if (c.ind + direct < best) { best = c.ind + direct; best_x = c.x; }
+            if (!is_leaf(c.x)) {
+                const double ind = c.ind + direct - area_of(c.x);
+                if (ind + ax < best) {
+                    int k0 = t[c.x].child[0], k1 = t[c.x].child[1];
+                    if (c.x == G) { if (k0 == P) k0 = S; else k1 = S; } // (P is gone: its sibling hangs under G)
+                    if (k0 > k1) std::swap(k0, k1);
+                    for (int k : {k0, k1}) { w.heap.push_back(Cand{ind, k}); std::push_heap(w.heap.begin(), w.heap.end(), cmp); }
+                }
+            }
+        }
+        for (int y : w.path) w.pidx[y] = -1;
+        out.best_x = best_x;
+    };
+    std::vector<Work> work((size_t)n_threads);
+    for (Work& w : work) w.pidx.assign((size_t)n_all, -1);
+    // a pool of n_threads - 1 helpers; the calling thread works too.  The helpers SPIN between blocks (a block is under a millisecond of
+    // work: waking a sleeping thread takes about as long, and the helpers then find the block done) -- for the few tens of milliseconds of a pass
+    struct Pool {
+        std::vector<std::thread> th;
+        std::atomic<int> gen{0}, running{0};
+        std::atomic<bool> quit{false};
+        const std::function<void(int)>* job = nullptr;
+    } pool;
+    for (int k = 1; k < n_threads; k++)
+        pool.th.emplace_back([&pool, k] {
+            int seen = 0;
+            for (;;) {
+                int spins = 0;
+                while (pool.gen.load(std::memory_order_acquire) == seen && !pool.quit.load(std::memory_order_acquire))
+                    if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+                if (pool.quit.load(std::memory_order_acquire)) return;
+                seen = pool.gen.load(std::memory_order_acquire);
+                (*pool.job)(k);
+                pool.running.fetch_sub(1, std::memory_order_acq_rel);
+            }
+        });
+    auto run_all = [&](const std::function<void(int)>& job) {
+        if (n_threads > 1) {
+            pool.job = &job;
+            pool.running.store(n_threads - 1, std::memory_order_release);
+            pool.gen.fetch_add(1, std::memory_order_acq_rel);
+        }
+        job(0);
+        if (n_threads > 1) {
+            int spins = 0;
+            while (pool.running.load(std::memory_order_acquire) != 0)
+                if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+        }
+    };
+    const int BLOCK = 512;
+    std::vector<Spec> spec((size_t)BLOCK);
+    int block_id = 0;
+    for (int pass = 0; pass < passes; pass++) {
+        std::vector<int> order;
+        for (int x = 0; x < n_all; x++)
+            if (x != root && t[x].parent != root) order.push_back(x);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a].area != t[b].area ? t[a].area > t[b].area : a < b; });
+        for (size_t b0 = 0; b0 < order.size(); b0 += BLOCK, block_id++) {
+            const int nb = (int)std::min<size_t>(BLOCK, order.size() - b0);
+            std::atomic<int> next{0};
+            run_all([&](int tid) {
+                for (;;) {
+                    const int i0 = next.fetch_add(8);
+                    if (i0 >= nb) break;
+                    for (int i = i0; i < std::min(nb, i0 + 8); i++) search(order[b0 + (size_t)i], work[(size_t)tid], spec[(size_t)i]);
+                }
+            });
+            for (int i = 0; i < nb; i++) {
+                const int x = order[b0 + (size_t)i];
+                Spec& sp = spec[(size_t)i];
+                bool stale = false;
+                for (int y : sp.read) if (stamp[(size_t)y] == block_id) { stale = true; break; }
+                if (stale) search(x, work[0], sp);
+                const int P = t[x].parent;
+                if (P < 0 || P == root || sp.best_x < 0) continue;
+                const int S = t[P].child[0] == x ? t[P].child[1] : t[P].child[0];
+                if (sp.best_x == S) { // stays: the serial pass leaves the pair as (sibling, node)
+                    t[P].child[0] = S; t[P].child[1] = x;
+                    continue;
+                }
+                // moves: out of its place (the sibling goes up), in beside best_x; every node whose box or links change is stamped
+                const int G = t[P].parent;
+                t[G].child[t[G].child[0] == P ? 0 : 1] = S;
+                t[S].parent = G;
+                stamp[(size_t)G] = stamp[(size_t)S] = stamp[(size_t)P] = stamp[(size_t)x] = block_id;
+                for (int y = G; y >= 0; y = t[y].parent) {
+                    Box bb = t[t[y].child[0]].box;
+                    bb.grow(t[t[y].child[1]].box);
+                    if (same_box(bb, t[y].box)) break;
+                    t[y].box = bb; t[y].area = bb.half_area(); stamp[(size_t)y] = block_id;
+                }
+                const int bxn = sp.best_x;
+                const int Q = t[bxn].parent;
+                t[P].child[0] = bxn; t[P].child[1] = x;
+                t[P].parent = Q;
+                t[bxn].parent = P; t[x].parent = P;
+                stamp[(size_t)bxn] = block_id;
+                if (Q >= 0) { t[Q].child[t[Q].child[0] == bxn ? 0 : 1] = P; stamp[(size_t)Q] = block_id; }
+                else root = P;
+                bool first = true;
+                for (int y = P; y >= 0; y = t[y].parent, first = false) {
+                    Box bb = t[t[y].child[0]].box;
+                    bb.grow(t[t[y].child[1]].box);
+                    if (!first && same_box(bb, t[y].box)) break;
+                    t[y].box = bb; t[y].area = bb.half_area(); stamp[(size_t)y] = block_id;
+                }
+            }
+        }
+    }
+    pool.quit.store(true, std::memory_order_release);
+    for (std::thread& th : pool.th) th.join();
+    // back to the breadth-first array of inner nodes
+    std::vector<int> order, index((size_t)n_all, -1), dep;
+    order.push_back(root); dep.push_back(1); index[root] = 0;
+    int md = 2;
+    for (size_t q = 0; q < order.size(); q++)
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int c = t[order[q]].child[s2];
+            md = std::max(md, dep[q] + 1);
+            if (!is_leaf(c)) { index[c] = (int)order.size(); order.push_back(c); dep.push_back(dep[q] + 1); }
+        }
+    std::vector<Node> out(order.size());
+    for (size_t q = 0; q < order.size(); q++)
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int c = t[order[q]].child[s2];
+            out[q].box[s2] = t[c].box;
+            out[q].child[s2] = is_leaf(c) ? t[c].leaf_ref : index[c];
         }
     nodes.swap(out);
     return md;

@@ -1396,14 +1396,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const bool done4 = inner_step_dec_x<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
                                                                        lq_free, nullptr, &voided);
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
-#ifdef CRT_MERGE_BRANCHES
-                    if (en && !voided) { ref = ref4; sp = sp4; done = done4; }
-#else
-                    {   // (selects, not a branch around three moves: the exec-mask save / restore of such a region costs more than it skips)
+                    {   // (selects, not a branch around three moves: 12 scalar instructions fewer per step for 10 vector ones more; measured level, round 5)
                         const bool take4 = en & !voided;
                         ref = take4 ? ref4 : ref; sp = take4 ? sp4 : sp; done = take4 ? done4 : done;
                     }
-#endif
                     if (STATS && en && voided) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
@@ -1423,15 +1419,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                             uint32_t n2 = 0;
                             int ref5 = ref, sp5 = sp;
                             const bool done5 = inner_step_dec_x<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
-#ifdef CRT_MERGE_BRANCHES
-                            if (!bailed && en2) { ref = ref5; sp = sp5; done = done5; n_leaf += n2; any_leaf = any_leaf | any2; }
-#else
                             {
                                 const bool take5 = en2 & !bailed;
                                 ref = take5 ? ref5 : ref; sp = take5 ? sp5 : sp; done = take5 ? done5 : done;
                                 n_leaf += take5 ? n2 : 0u; any_leaf = any_leaf | (take5 & any2);
                             }
-#endif
                             if (STATS && bailed && en2) dg_ov[1]++;
                         }
                     }
@@ -1643,7 +1635,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
-#ifdef CRT_CHAIN_LB_LC /* experiment: LB's roulette stops feed LC -- go there at once, without the scheduler, if LC now holds this many paths */
+#ifdef CRT_CHAIN_LB_LC /* experiment, not taken (round 5, VERDICT r04 item 5: "LB / LC one attempt"): LB's roulette stops feed LC -- go there at once,
+                          without the scheduler, if LC now holds this many paths.  16 / 32: C2 77.7 -> 80.0 / 78.2 ms, veach-mis spp 256 77.8 -> 78.9 / 78.6:
+                          the phase bodies run either way; what the chain changes is WHEN, and it runs LC with emptier batches than the
+                          fullest-first rule would */
             if (!commit_ring && qn[PH3_LC] >= CRT_CHAIN_LB_LC) act = PH3_LC;
 #endif
         }

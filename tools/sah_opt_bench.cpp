@@ -44,6 +44,25 @@ int main(int argc, char** argv)
         const auto t1 = clk::now();
         depth = crtaccel::optimize_sah(nodes, 1);
         const auto t2 = clk::now();
+        if (r == 0) { // the same pass on one thread and by the serial form of round 4: same tree whatever the threads; same summed area as the serial form
+            std::vector<crtaccel::Prim> p2 = prims0;
+            std::vector<crtaccel::Node> n1, ns;
+            int32_t r2 = 0;
+            crtaccel::build_sah(p2, n1, r2);
+            ns = n1;
+            const auto u0 = clk::now();
+            crtaccel::optimize_sah(n1, 1, 1);
+            const auto u1 = clk::now();
+            crtaccel::optimize_sah_serial(ns, 1);
+            const auto u2 = clk::now();
+            const bool same = n1.size() == nodes.size() && std::memcmp(n1.data(), nodes.data(), n1.size() * sizeof(crtaccel::Node)) == 0;
+            double as = 0, a1 = 0;
+            for (const auto& n : ns) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); as += b.half_area(); }
+            for (const auto& n : n1) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); a1 += b.half_area(); }
+            std::printf("{\"one_thread_equals_many\": %s, \"one_thread_ms\": %.2f, \"serial_round4_ms\": %.2f, \"summed_area_serial\": %.6e, \"summed_area_speculative\": %.6e, \"arrays_equal_serial\": %s}\n",
+                        same ? "true" : "false", std::chrono::duration<double, std::milli>(u1 - u0).count(), std::chrono::duration<double, std::milli>(u2 - u1).count(), as, a1,
+                        (ns.size() == n1.size() && std::memcmp(ns.data(), n1.data(), ns.size() * sizeof(crtaccel::Node)) == 0) ? "true" : "false");
+        }
         best_build = std::min(best_build, std::chrono::duration<double, std::milli>(t1 - t0).count());
         best_opt = std::min(best_opt, std::chrono::duration<double, std::milli>(t2 - t1).count());
         n_nodes = nodes.size();
