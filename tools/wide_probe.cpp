@@ -93,7 +93,7 @@ static WideTree collapse(const std::vector<crtaccel::Node>& bin, int W)
     return T;
 }
 
-struct Counts { unsigned long long visits = 0, boxes = 0, slots = 0, leaves = 0, rays = 0; };
+struct Counts { unsigned long long visits = 0, boxes = 0, slots = 0, leaves = 0, rays = 0, all_leaf = 0, no_leaf = 0; };
 static void walk(const WideTree& T, V3 o, V3 d, Counts& c)
 {
     const V3 inv = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
@@ -102,6 +102,7 @@ static void walk(const WideTree& T, V3 o, V3 d, Counts& c)
     while (!st.empty()) {
         const Wide& w = T.nodes[st.back()]; st.pop_back();
         c.visits++; c.slots += (unsigned long long)T.W; c.boxes += w.box.size();
+        { size_t nl = 0; for (int32_t r : w.ref) nl += r < 0; c.all_leaf += nl == w.ref.size(); c.no_leaf += nl == 0; }
         for (size_t i = 0; i < w.box.size(); i++)
             if (hit_box(w.box[i], o, inv, d)) { if (w.ref[i] >= 0) st.push_back(w.ref[i]); else c.leaves++; }
     }
@@ -194,11 +195,11 @@ int main(int argc, char** argv)
         }
         unsigned long long children = 0, inner_children = 0;
         for (const Wide& w : T.nodes) { children += w.box.size(); for (int32_t r : w.ref) inner_children += r >= 0; }
-        Counts a; for (int k = 0; k < 3; k++) { a.visits += c[k].visits; a.boxes += c[k].boxes; a.slots += c[k].slots; a.leaves += c[k].leaves; a.rays += c[k].rays; }
+        Counts a; for (int k = 0; k < 3; k++) { a.all_leaf += c[k].all_leaf; a.no_leaf += c[k].no_leaf; a.visits += c[k].visits; a.boxes += c[k].boxes; a.slots += c[k].slots; a.leaves += c[k].leaves; a.rays += c[k].rays; }
         std::printf("{\"W\": %d, \"wide_nodes\": %zu, \"children_per_node\": %.2f, \"summed_area\": %.5e, \"visits_per_ray\": %.3f, \"child_slots_per_ray\": %.2f, "
-                    "\"real_children_per_ray\": %.2f, \"leaf_boxes_hit_per_ray\": %.3f, \"by_kind_visits\": {\"camera\": %.2f, \"bounce\": %.2f, \"to_light\": %.2f}}\n",
+                    "\"real_children_per_ray\": %.2f, \"leaf_boxes_hit_per_ray\": %.3f, \"visits_at_nodes_whose_children_are_all_leaves\": %.3f, \"visits_at_nodes_without_leaf_children\": %.3f, \"by_kind_visits\": {\"camera\": %.2f, \"bounce\": %.2f, \"to_light\": %.2f}}\n",
                     W, T.nodes.size(), (double)children / T.nodes.size(), T.summed_area, (double)a.visits / a.rays, (double)a.slots / a.rays, (double)a.boxes / a.rays,
-                    (double)a.leaves / a.rays, (double)c[0].visits / std::max(1ull, c[0].rays), (double)c[1].visits / std::max(1ull, c[1].rays), (double)c[2].visits / std::max(1ull, c[2].rays));
+                    (double)a.leaves / a.rays, (double)a.all_leaf / a.visits, (double)a.no_leaf / a.visits, (double)c[0].visits / std::max(1ull, c[0].rays), (double)c[1].visits / std::max(1ull, c[1].rays), (double)c[2].visits / std::max(1ull, c[2].rays));
     }
     return 0;
 }
