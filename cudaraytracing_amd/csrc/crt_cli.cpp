@@ -106,6 +106,7 @@ int main(int argc, char** argv)
             std::printf("ranks: %u, gather: %s, rccl ranks: %u (rccl %d), %llu B per rank, render %.3f ms + gather %.3f ms\n", mi.n_ranks,
                         mi.gather == CRT_GATHER_RCCL ? "rccl" : "copy", mi.rccl_ranks, mi.rccl_version, (unsigned long long)mi.bytes_per_rank,
                         mi.render_ms, mi.gather_ms);
+            if (mi.fallback_reason[0]) std::printf("gather fell back to peer copies: %s\n", mi.fallback_reason);
         }
         render.save_frame_buffer(out.c_str());
         std::printf("%s\n", out.c_str());
