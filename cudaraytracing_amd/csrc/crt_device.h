@@ -72,8 +72,6 @@ struct DevScene {
     int32_t rootw;
     uint32_t emptyw_off;
 #endif
-    uint32_t one_record;     // 1: no leaf has more than two triangles (bvh_thresh_n <= 2, both shipped configs), i.e. every leaf is ONE record of
-                             // leaf_geo: the decoupled leaf step then runs without its loop over a leaf's records (in the struct's tail padding)
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

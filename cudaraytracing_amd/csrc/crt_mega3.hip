@@ -1492,26 +1492,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float bt = 0.0f;
                 int bi = 0;
                 int left = 1;
-#ifdef CRT_ONE_RECORD /* experiment, not taken (round 5): C2 78.55 / 78.33 -> 78.66 / 78.92 ms, veach-mis spp 256 77.87 / 77.93 -> 78.04 / 78.08 -- eleven
-                         instructions fewer per leaf step, and the second copy of the pair test in the kernel costs what they save */
-                // (no leaf of the scene has more than two triangles -- bvh_thresh_n <= 2, both shipped configs: a leaf IS one record, and the
-                // step runs without the loop over a leaf's records, its exec-mask bookkeeping and the running best; a wave-uniform branch)
-                if (sc.one_record) {
-                    const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
-                    const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
-                    const int it = __float_as_int(g4.z);
-                    const bool two = __float_as_int(g4.w) > 1;
-                    bool a0, a1;
-                    float t0, t1;
-                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
-                    if (STATS) { tc.tests += two ? 2u : 1u; }
-                    const bool b0 = a0 & (Tl - t0 > CRT_EPSILON);
-                    const bool b1 = a1 & two & (Tl - t1 > CRT_EPSILON);
-                    const bool s1 = b1 & (!b0 | (t1 < t0));
-                    bt = s1 ? t1 : t0; bi = s1 ? it + 1 : it; have = b0 | b1;
-                    left = 0;
-                }
-#endif
+                // (a leaf step without this loop for scenes whose leaves are one record each -- bvh_thresh_n <= 2 -- was measured in round 5: eleven
+                // instructions fewer per step, C2 +0.3 %, veach-mis +0.2 %: the second copy of the pair test costs what they save; not kept)
                 for (int k = 0; left > 0; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
                     const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
                     const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
@@ -1635,12 +1617,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
-#ifdef CRT_CHAIN_LB_LC /* experiment, not taken (round 5, VERDICT r04 item 5: "LB / LC one attempt"): LB's roulette stops feed LC -- go there at once,
-                          without the scheduler, if LC now holds this many paths.  16 / 32: C2 77.7 -> 80.0 / 78.2 ms, veach-mis spp 256 77.8 -> 78.9 / 78.6:
-                          the phase bodies run either way; what the chain changes is WHEN, and it runs LC with emptier batches than the
-                          fullest-first rule would */
-            if (!commit_ring && qn[PH3_LC] >= CRT_CHAIN_LB_LC) act = PH3_LC;
-#endif
+            // (going from here straight to LC when LC holds 16 / 32 paths -- LB's roulette stops feed it -- was measured in round 5: C2 +3.0 % / +0.7 %,
+            // veach-mis +1.4 % / +1.0 %: it runs LC with emptier batches than the fullest-first rule; not kept)
         }
         if (act != PH3_LA && act != PH3_LB) {
             // LC, or -- commit ring -- a look at the slots that are held back (PH3_WAIT), through the same code: the held slots have

@@ -1171,7 +1171,6 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->dev.tri_nm = sc->tri_nm.p;
         sc->max_leaf = max_leaf;
         sc->dev.nodes3 = sc->nodes3.p; sc->dev.leaf_geo = sc->leaf_geo.p;
-        sc->dev.one_record = max_leaf <= 2 ? 1u : 0u;
         sc->dev.root3_fast = ref3(root_fast); sc->dev.root3_exact = ref3(root_exact);
         std::vector<uint4> lights(d->n_lights);
         for (uint32_t i = 0; i < d->n_lights; i++) {
