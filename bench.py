@@ -272,6 +272,29 @@ def pick_bound(bounds):
     return best, best_f
 
 
+def device_identity(torch, device):
+    """(63-bit key, what it was made of) of the physical GPU behind `device` on this host: a hash over the host name and the device's
+    UUID (torch.cuda.get_device_properties(...).uuid), else over its PCI domain:bus:device; (None, reason) when neither can be read."""
+    import hashlib
+    props = None
+    try:
+        props = torch.cuda.get_device_properties(device)
+    except Exception as e:
+        return None, "get_device_properties failed: %s" % type(e).__name__
+    ident, src = None, None
+    u = getattr(props, "uuid", None)
+    if u is not None and str(u).strip("0-") != "":
+        ident, src = "uuid:" + str(u), "host name + device UUID"
+    else:
+        dom, bus, dev = (getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+        if bus is not None and int(bus) >= 0:
+            ident, src = "pci:%s:%s:%s" % (dom, bus, dev), "host name + PCI domain:bus:device"
+    if ident is None:
+        return None, "neither a UUID nor a PCI bus id is exposed"
+    h = hashlib.sha256((socket.gethostname() + "|" + ident).encode()).digest()
+    return int.from_bytes(h[:8], "little") >> 1, src
+
+
 def main_rank(args):
     import numpy as np
     import torch
@@ -314,15 +337,17 @@ def main_rank(args):
     if world > 1:
         ones = torch.ones(1, dtype=torch.int32, device=(torch.device("cpu") if backend == "gloo" else device))
         dist.all_reduce(ones)
-        try:
-            bus = torch.cuda.get_device_properties(device).pci_bus_id
-        except Exception:
-            bus = -1
-        mine = torch.tensor([int(bus), int(local_rank)], dtype=torch.int32, device=ones.device)
+        # the PHYSICAL device of every rank, and nothing else, is the key (a key that holds the local rank counts ranks, not
+        # devices): 8 bytes of a hash over (host name, the device's UUID -- or its PCI domain:bus:device where this torch exposes no UUID);
+        # a rank that can read neither contributes "unknown" and the count is then reported as None, never as a number
+        dev_key, dev_id_src = device_identity(torch, device)
+        mine = torch.tensor([dev_key if dev_key is not None else 0, 0 if dev_key is not None else 1], dtype=torch.int64, device=ones.device)
         allb = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allb, mine)
+        unknown = sum(int(t[1]) for t in allb)
         collective_proof = {"backend": backend, "ranks_counted_by_all_reduce": int(ones.item()),
-                            "distinct_devices": len({(int(t[0]), int(t[1])) for t in allb})}
+                            "distinct_devices": (len({int(t[0]) for t in allb}) if unknown == 0 else None),
+                            "device_identity": dev_id_src, "ranks_with_unknown_device": unknown}
 
     def barrier():
         if world > 1:
@@ -438,7 +463,7 @@ def main_rank(args):
             radiance_storage = None
     red_dev = torch.device("cpu") if one_device else device
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    r = torch.tensor([float(rays_local)], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([float(rays_local), float(untraced_local)], dtype=torch.float64, device=red_dev)
     # per-rank view of a step (for reading a scaling curve): this rank's mean kernel time per frame, gathered from all ranks
     k_local = float(np.mean([k for k in kernel_ms if k is not None])) if any(k is not None for k in kernel_ms) else 0.0
     k_all = torch.zeros(max(1, world), dtype=torch.float64, device=red_dev)
@@ -451,9 +476,15 @@ def main_rank(args):
     if multi and mr is not None and mr.rank_stats:
         rank_kernel_ms = [float(s_["kernel_ms"]) for s_ in mr.rank_stats]
     elapsed = float(t.item())
-    rays_frame = float(r.item())
+    rays_frame, untraced_frame = float(r[0].item()), float(r[1].item())
+    if multi:   # (one process: its counters are the frame's)
+        untraced_frame = float(untraced_local)
     ms_per_step = elapsed * 1e3 / args.steps
-    mrays = rays_frame * args.steps / elapsed / 1e6
+    # Two rates.  `value` counts the rays that WERE TRACED: next-event samples whose contribution is exactly zero are
+    # answered without traversal (same frame bit for bit) and are a ray of the reference but no work of this kernel.  The rate over the
+    # reference's own ray count ("one call of DeviceBVH::intersect") is `value_reference_rays`.
+    mrays_ref = rays_frame * args.steps / elapsed / 1e6
+    mrays = (rays_frame - untraced_frame) * args.steps / elapsed / 1e6
     n_gpus = args.gpus
     single = n_gpus == 1
 
@@ -613,8 +644,8 @@ def main_rank(args):
             r3.traversal = trav
             c3 = {"workload": "veach-mis 800x600 spp=1024 P_RR=%g light_sample_n=%d" % (float(t3.P_RR), t3.light_sample_n), "frames": 3,
                   "ms_per_frame": round(dt3 * 1e3, 3), "kernel_ms": round(float(np.mean(k3)), 3), "rays_per_frame": int(st3["rays"]),
-                  "mrays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
-                  "mrays_traced_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),
+                  "mrays_per_sec": round((st3["rays"] - st3["rays_untraced"]) / dt3 / 1e6, 2),   # rays traced (as `value`)
+                  "mrays_reference_rays_per_sec": round(st3["rays"] / dt3 / 1e6, 2),
                   "untraced_frac": round(st3["rays_untraced"] / st3["rays"], 4),
                   "all_rays_traced_ms": round(dt3a * 1e3, 3), "value_all_rays_traced": round(st3a["rays"] / dt3a / 1e6, 2),
                   ("fast_mode_ms" if other3 == crt.TRAVERSAL_FAST else "exact_mode_ms"): round(dt3e * 1e3, 3)}
@@ -729,7 +760,7 @@ def main_rank(args):
         elif world > 1 and backend == "nccl":
             rccl_ranks = int(collective_proof["ranks_counted_by_all_reduce"])
             rccl_evidence = dict(collective_proof, source="sum of a device tensor of ones all-reduced over the RCCL process group (torch exposes no ncclCommCount); "
-                                                         "distinct_devices = PCI bus ids all-gathered over the same group")
+                                                         "distinct_devices = physical-device keys (host name + UUID / PCI address) all-gathered over the same group")
         line = {
             "metric": "Mrays/sec", "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
@@ -744,7 +775,11 @@ def main_rank(args):
                        "untraced_samples": "next-event samples whose contribution is exactly zero are answered without traversal "
                                            "(frame bit-identical, still counted as rays of the reference): %.1f%% of the rays%s; "
                                            "`all_rays_traced` times the same frame with every one of them traced"
-                                           % (100.0 * untraced_local / max(1, rays_local), "" if multi else " on rank 0")},
+                                           % (100.0 * untraced_frame / max(1.0, rays_frame), "")},
+            "value_definition": "rays TRACED per second (reference rays minus the zero-contribution next-event samples answered without traversal); "
+                                "`value_reference_rays` divides the reference's own ray count by the same time; ms_per_step is the figure that compares across implementations",
+            "value_reference_rays": round(mrays_ref, 2),
+            "rays_traced_per_frame": int(rays_frame - untraced_frame),
             "frames_per_sec": round(1e3 / ms_per_step, 4),
             "frames_in_flight": 2 if pipelined else 1,
             "frames_without_kernel_time": kernel_ms_missing,
@@ -763,8 +798,7 @@ def main_rank(args):
             "workload_id": wl,
             "radiance_storage": radiance_storage,
             "scene_setup": setup,
-            "rays_untraced_per_frame_rank0": int(untraced_local),
-            "mrays_traced_per_sec": round((rays_frame - untraced_local) * args.steps / elapsed / 1e6, 2) if (single or multi) else None,
+            "rays_untraced_per_frame": int(untraced_frame),
             "all_rays_traced": all_traced,
             # the same numbers with EVERY ray of the reference traced (no zero-contribution samples answered without traversal):
             # the figures to compare with tracers that count only rays they trace

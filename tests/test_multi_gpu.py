@@ -151,7 +151,9 @@ def test_bench_c4_resolution_on_four_self_started_ranks(single, tmp_path):
     assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["collective"]["launched_by"].startswith("bench.py")
     ev = line["collective"]["rccl_evidence"]
     assert line["collective"]["backend"] == "gloo" and line["collective"]["rccl_ranks"] == 0 and ev is None
-    assert line["collective"]["proof"]["ranks_counted_by_all_reduce"] == 4  # (one device here: distinct_devices counts (bus id, local rank) pairs)
+    assert line["collective"]["proof"]["ranks_counted_by_all_reduce"] == 4
+    assert line["collective"]["proof"]["distinct_devices"] == 1   # (four ranks on ONE physical device: the key is the device, not the rank -- ADVICE r05)
+    assert line["collective"]["proof"]["ranks_with_unknown_device"] == 0
     pr = line["per_rank"]
     assert 0 < pr["kernel_ms_min"] <= pr["kernel_ms_max"] and "non_kernel_ms_per_step" in pr
     eye, iv, fov = util.camera("cornell-box")

@@ -12,6 +12,13 @@ conservative.  The counter buffer's address arrives in the two kernel-argument d
 dbg_valu, unused by the production build); counter i lives at byte i * 128 and the buffer must not cross a 4 GiB boundary
 (the host hook sees to that).  blocks.json describes every block: label, opcode histogram, source lines.
 
+A counted unit is a SEGMENT: a basic block cut again behind every instruction that rewrites exec (the `s_or_b64 exec, exec, sN`
+that opens a join block, an `s_and_saveexec_b64` whose branch the compiler left out, `s_mov_b64 exec, ...`, `v_cmpx_*`), so that
+every vector instruction is counted with the exec mask it runs under.  (Until round 5 the prologue stood before a block's first
+instruction: a join block was sampled with the mask of the arm that fell into it -- 13 % of the dynamic vector instructions sat in
+such blocks and 40 % of the census's lost lanes were theirs.)  A segment that would begin with a branch is not opened: the branch
+stays with the segment before it (no vector instruction is affected).  Segments of one block are labelled <label>, <label>+1, ...
+
 The other kernels of the translation unit are dropped from <out.s>: the code object holds the one instrumented kernel.
 """
 import collections
@@ -76,7 +83,17 @@ def main():
             return "salu"
         return "other"
 
+    def writes_exec(s):
+        """Does this instruction rewrite the exec mask?  (destination operand exec / exec_lo / exec_hi, the *_saveexec_* forms, v_cmpx_*)"""
+        mn = s.split()[0]
+        if "saveexec" in mn or mn.startswith("v_cmpx"):
+            return True
+        ops = s[len(mn):].split(";", 1)[0].split(",")
+        return bool(ops) and re.match(r"^\s*exec(_lo|_hi)?\s*$", ops[0]) is not None and not mn.startswith(("s_cmp", "s_bitcmp", "v_cmp", "s_cbranch", "s_waitcnt"))
+
     label_of_next = None
+    split_pending = False    # the instruction before this one rewrote exec: what follows is a segment of its own (unless it is a branch)
+    seg_base, seg_k = None, 0
     for idx, l in enumerate(body):
         s = l.strip()
         m = re.match(r"^(\.LBB\d+_\d+):", l)
@@ -99,9 +116,16 @@ def main():
             out.append(l)
             continue
         mn = s.split()[0]
+        if split_pending and not pending_new and classify(mn) != "branch" and mn != "s_endpgm":
+            seg_k += 1
+            cur = {"id": len(blocks), "label": "%s+%d" % (seg_base, seg_k), "instrs": [], "locs": collections.Counter(), "after_exec_write": True}
+            blocks.append(cur)
+            out.append("@@PROLOGUE %d@@" % cur["id"])
+        split_pending = False
         if pending_new:
             cur = {"id": len(blocks), "label": label_of_next or ("fall%d" % len(blocks)), "instrs": [], "locs": collections.Counter()}
             blocks.append(cur)
+            seg_base, seg_k = cur["label"], 0
             label_of_next = None
             pending_new = False
             out.append("@@PROLOGUE %d@@" % cur["id"])
@@ -112,6 +136,8 @@ def main():
         out.append(l)
         if classify(mn) == "branch" or mn == "s_endpgm":
             pending_new = True
+        elif writes_exec(s):
+            split_pending = True
 
     # ---- registers ----
     desc = lines[end:tail + 1]
