@@ -32,10 +32,6 @@ namespace crtdev {
 #define CRT_BOUNCE_STACK_SIZE 64   /* reference: include/Global.h:18 */
 #define CRT_TILE 8                 /* pixel tile edge used for sharding */
 
-#ifndef CRT_WIDE
-#define CRT_WIDE 4 /* children per node of the tree the decoupled-leaves kernels walk: 4 = nodes4 (production); 6 / 8: experiment builds (round 5) */
-#endif
-
 struct DevScene {
     const float4* nodes;
     const float4* tri_geo;
@@ -67,11 +63,6 @@ struct DevScene {
     float coord_max;         // largest |coordinate| of a box of the 4-wide tree, +inf if one is not finite (start_ray: which rays may walk it)
     const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
     uint32_t empty4_off;     // byte offset in nodes4 of a node of four empty slots, behind the tree (the decoupled-leaves step parks idle lanes there)
-#if CRT_WIDE != 4
-    const float4* nodesw;    // (-DCRT_WIDE=6 / 8, experiment builds) the tree of the decoupled-leaves kernels: CRT_WIDE children per node, crt_render.hip
-    int32_t rootw;
-    uint32_t emptyw_off;
-#endif
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

@@ -186,7 +186,7 @@ struct MParams3 {
     int32_t dbg_loads, dbg_valu; // unused by the kernel; tools/bbprof passes the address of its counter buffer in these two dwords
 };
 
-static_assert(CRT_WIDE != 4 || (offsetof(MParams3, dbg_loads) == 668 && offsetof(MParams3, dbg_valu) == 672), "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
+static_assert(offsetof(MParams3, dbg_loads) == 668 && offsetof(MParams3, dbg_valu) == 672, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
 
 
 // ---- exported by crt_mega3.hip ----

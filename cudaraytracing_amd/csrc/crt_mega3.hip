@@ -8,10 +8,6 @@
 #include <cstring>
 #include <vector>
 
-#ifndef CRT_X_BOOLMASK
-#define CRT_X_BOOLMASK 1 /* decoupled inner step: the children's accept tests and everything derived from them as wave masks in scalar registers (round 5; 0 = the round-4 form) */
-#endif
-
 namespace crtk {
 
 struct NewRay {
@@ -116,11 +112,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     const bool finite = ((sc.coord_max + max_o) * max_inv <= 0x1p126f) & finite3(nr.d.x, nr.d.y, nr.d.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
     // (MODE 0 / 2: a ray that is not RF_EXACT walks the 4-wide tree)
-#if CRT_WIDE != 4
-    const int ref = (MODE != 1 && finite && !force_exact) ? (LDS::DEC ? sc.rootw : sc.root4) : sc.root3_exact;
-#else
     const int ref = (MODE != 1 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
-#endif
     bool answered = false;
     float T = FLT_MAX;
     if (MODE != 1 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
@@ -594,19 +586,35 @@ __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 f
     }
 }
 
+// (plane pair - o_axis) * inv_axis for two children at once, with the ray's scalar BROADCAST by the instruction's own operand selects
+// (op_sel / op_sel_hi pick the low or the high half of a 64-bit register pair for both result halves): the reference's two roundings per
+// plane (DeviceBVH.cuh:95-100), and no move that builds a (x, x) pair -- left to itself the compiler builds such pairs for half of these
+// instructions (nine v_mov per visit in round 5, and the duplicates cost registers: the second visit's 1 / d went to scratch memory).
+// HALF: 0 = the scalar is the pair's low half, 1 = its high half.
+#define CRT_PK_SUBMUL_IMPL(OH, IH)                                                                                          \
+    v2f d_;                                                                                                                 \
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0," #OH "] op_sel_hi:[1," #OH "] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d_) : "v"(p), "v"(o)); \
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0," #IH "] op_sel_hi:[1," #IH "]" : "=v"(d_) : "v"(d_), "v"(i));                    \
+    return d_;
+__device__ __forceinline__ v2f pk_submul_ll(const v2f p, const v2f o, const v2f i) { CRT_PK_SUBMUL_IMPL(0, 0) }
+__device__ __forceinline__ v2f pk_submul_hh(const v2f p, const v2f o, const v2f i) { CRT_PK_SUBMUL_IMPL(1, 1) }
+#undef CRT_PK_SUBMUL_IMPL
+// the ray as the 4-wide step keeps it: (o.x, o.y), (o.z, -) and (1/d.x, 1/d.y), (1/d.z, -) in aligned register pairs
+struct RayPk { v2f oxy, oz, ixy, iz; };
+
 // The same four boxes with the accept test of hit_AABB (DeviceBVH.cuh:121-125) handed back as predicates beside the entry distances:
 // the decoupled step needs "hit" as a wave mask (its leaf-queue appends) and as a lane predicate, and the distance only to put the
 // nearest inner child first -- a distance forced to +inf and compared with +inf again costs a select and a compare per child.
 __device__ __forceinline__ void slab_quad_hits(const float4 nx, const float4 fx, const float4 ny, const float4 fy, const float4 nz, const float4 fz,
-                                               const F3 o, const F3 inv, float& e0, float& e1, float& e2, float& e3,
+                                               const RayPk& R, float& e0, float& e1, float& e2, float& e3,
                                                unsigned long long& h0, unsigned long long& h1, unsigned long long& h2, unsigned long long& h3)
 {
-    const v2f nxa = (v2(nx.x, nx.y) - v2s(o.x)) * v2s(inv.x), nxb = (v2(nx.z, nx.w) - v2s(o.x)) * v2s(inv.x);
-    const v2f nya = (v2(ny.x, ny.y) - v2s(o.y)) * v2s(inv.y), nyb = (v2(ny.z, ny.w) - v2s(o.y)) * v2s(inv.y);
-    const v2f nza = (v2(nz.x, nz.y) - v2s(o.z)) * v2s(inv.z), nzb = (v2(nz.z, nz.w) - v2s(o.z)) * v2s(inv.z);
-    const v2f fxa = (v2(fx.x, fx.y) - v2s(o.x)) * v2s(inv.x), fxb = (v2(fx.z, fx.w) - v2s(o.x)) * v2s(inv.x);
-    const v2f fya = (v2(fy.x, fy.y) - v2s(o.y)) * v2s(inv.y), fyb = (v2(fy.z, fy.w) - v2s(o.y)) * v2s(inv.y);
-    const v2f fza = (v2(fz.x, fz.y) - v2s(o.z)) * v2s(inv.z), fzb = (v2(fz.z, fz.w) - v2s(o.z)) * v2s(inv.z);
+    const v2f nxa = pk_submul_ll(v2(nx.x, nx.y), R.oxy, R.ixy), nxb = pk_submul_ll(v2(nx.z, nx.w), R.oxy, R.ixy);
+    const v2f nya = pk_submul_hh(v2(ny.x, ny.y), R.oxy, R.ixy), nyb = pk_submul_hh(v2(ny.z, ny.w), R.oxy, R.ixy);
+    const v2f nza = pk_submul_ll(v2(nz.x, nz.y), R.oz, R.iz), nzb = pk_submul_ll(v2(nz.z, nz.w), R.oz, R.iz);
+    const v2f fxa = pk_submul_ll(v2(fx.x, fx.y), R.oxy, R.ixy), fxb = pk_submul_ll(v2(fx.z, fx.w), R.oxy, R.ixy);
+    const v2f fya = pk_submul_hh(v2(fy.x, fy.y), R.oxy, R.ixy), fyb = pk_submul_hh(v2(fy.z, fy.w), R.oxy, R.ixy);
+    const v2f fza = pk_submul_ll(v2(fz.x, fz.y), R.oz, R.iz), fzb = pk_submul_ll(v2(fz.z, fz.w), R.oz, R.iz);
     e0 = fmax3(nxa.x, nya.x, nza.x); e1 = fmax3(nxa.y, nya.y, nza.y); e2 = fmax3(nxb.x, nyb.x, nzb.x); e3 = fmax3(nxb.y, nyb.y, nzb.y);
     const float x0 = fmin3(fxa.x, fya.x, fza.x), x1 = fmin3(fxa.y, fya.y, fza.y), x2 = fmin3(fxb.x, fyb.x, fzb.x), x3 = fmin3(fxb.y, fyb.y, fzb.y);
     // (a wave mask per child: the AND of the two compares' own results -- a ballot of their conjunction would cost a select and a compare)
@@ -796,19 +804,43 @@ __device__ __forceinline__ void leafq_push_all(LDS& S, const bool hit, const uns
     S.leafq[hit ? (slot & (uint32_t)(LEAFQ_CAP - 1)) : (uint32_t)LEAFQ_CAP] = entry;
     tail += (uint32_t)__popcll(m);
 }
+// ---- wave masks (round 6) ----
+// A predicate of the traversal steps lives as a WAVE MASK in a scalar register pair from the compare that makes it to the select, store or
+// count that uses it: a ballot of a compare is the compare's own result, conjunctions / disjunctions / counts are scalar instructions, and
+// `lanes` hands a mask back to the vector unit as it stands.  The compiler's own treatment of a bool that crosses a join or is combined
+// before a ballot is a trip through a vector register (v_cndmask 0 / 1, v_cmp_ne: 3 % of the kernel's vector instructions in round 5).
+typedef unsigned long long wmask;
+__device__ __forceinline__ wmask bal(const bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool lanes(const wmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// x + 1 / x - 1 in the lanes of m: the mask rides in as the carry (one instruction; the compiler's form is a select and an addition)
+__device__ __forceinline__ int add_mask(const int x, const wmask m)
+{
+    int r;
+    wmask co;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(co) : "v"(x), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int sub_mask(const int x, const wmask m)
+{
+    int r;
+    wmask co;
+    asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(co) : "v"(x), "s"(m));
+    return r;
+}
+
 // CHECK: what happens when the queue cannot take the visit's entries (they are counted before anything is written).  0: cannot happen (the
 // caller cut the batch to a quarter of the free entries); 1: the lanes from `cap_left / 4` on are taken out of the visit (*voided: they keep
 // their state and are queued again); 2: the whole visit is dropped (*bailed).
+// EN: the lanes that take the step.  A lane outside it -- a lane without a ray, an any-hit ray that has its answer, a ray of the
+// reference-arithmetic path, a voided lane -- steps at the EMPTY node and keeps its node and depth: it hits nothing, appends nothing,
+// pushes nothing and does not pop.  Returns the lanes whose walk is over (a subset of EN); n_leaf and any_leaf accumulate.
 template <bool STATS, class LDS, int CHECK = 0>
-__device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 dir,
-                                                int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
-                                                uint32_t& n_leaf, const bool enable, const uint32_t cap_left = 0, bool* bailed = nullptr, bool* voided = nullptr)
+__device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 dir, RayPk& R,
+                                                 int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, wmask& any_leaf,
+                                                 int& n_leaf, const wmask EN, const uint32_t cap_left = 0, bool* bailed = nullptr, wmask* voided = nullptr)
 {
-    // (every lane of the batch runs the step, so that the appends -- ballots, the running count `added` -- stay wave-uniform; a lane
-    // without `enable`, an any-hit ray that has its answer or a ray of the reference-arithmetic path, steps at the EMPTY node the host
-    // puts behind the tree -- four inverted boxes: nothing is hit, appended or pushed)
     const char* nb = (const char*)sc.nodes4;
-    const uint32_t noff = enable ? (uint32_t)ref * 128u : sc.empty4_off;
+    const uint32_t noff = lanes(EN) ? (uint32_t)ref * 128u : sc.empty4_off;
     // (the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
     const uint32_t ox = noff + ((__float_as_uint(dir.x) >> 27) & 16u), oy = noff + ((__float_as_uint(dir.y) >> 27) & 16u),
                    oz = noff + ((__float_as_uint(dir.z) >> 27) & 16u);
@@ -817,244 +849,76 @@ __device__ __forceinline__ bool inner4_step_dec(const DevScene& sc, LDS& S, cons
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 112);
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
-    const F3 inv = inv3_exact(dir);
+    if (CHECK != 2) { // (the second visit of a step takes the first one's 1 / d: the same value, and a ballot of a predicate of another block is a trip through a vector register)
+        const F3 inv = inv3_exact(dir);
+        R.ixy = v2(inv.x, inv.y); R.iz.x = inv.z;
+    }
     float t0, t1, t2, t3;
-    const float inf = pinf();
-    int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
-#if CRT_X_BOOLMASK
-    // The accept test as predicates, and everything that follows from them as WAVE MASKS in scalar registers (a ballot of a compare is
-    // the compare's own result; ANDs, the overflow cut and the counts are scalar instructions), turned back into lane predicates
-    // where a select or a store needs one (inverse ballot: the select reads the mask as it stands).
-    unsigned long long H0, H1, H2, H3;
-    slab_quad_hits(a0, a1, a2, b0, b1, b2, o, inv, t0, t1, t2, t3, H0, H1, H2, H3);
+    const int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    wmask H0, H1, H2, H3;
+    slab_quad_hits(a0, a1, a2, b0, b1, b2, R, t0, t1, t2, t3, H0, H1, H2, H3);
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-    const unsigned long long N0 = __builtin_amdgcn_ballot_w64(r0 < 0), N1 = __builtin_amdgcn_ballot_w64(r1 < 0), N2 = __builtin_amdgcn_ballot_w64(r2 < 0), N3 = __builtin_amdgcn_ballot_w64(r3 < 0);
+    const wmask N0 = bal(r0 < 0), N1 = bal(r1 < 0), N2 = bal(r2 < 0), N3 = bal(r3 < 0);
     uint32_t tail = lq_t + added;
-    unsigned long long m0 = H0 & N0, m1 = H1 & N1, m2 = H2 & N2, m3 = H3 & N3;         // leaf children that are hit
-    unsigned long long i0 = H0 & ~N0, i1 = H1 & ~N1, i2 = H2 & ~N2, i3 = H3 & ~N3;     // inner children that are hit
-    unsigned long long void_mask = 0ull;
+    wmask m0 = H0 & N0, m1 = H1 & N1, m2 = H2 & N2, m3 = H3 & N3;         // leaf children that are hit
+    wmask i0 = H0 & ~N0, i1 = H1 & ~N1, i2 = H2 & ~N2, i3 = H3 & ~N3;     // inner children that are hit
     if (CHECK != 0) {
         if ((uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)) > cap_left) {
-            if (CHECK == 2) { *bailed = true; return false; }
+            if (CHECK == 2) { *bailed = true; return 0ull; }
             // the lanes a quarter of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
-            const unsigned long long km = __builtin_amdgcn_ballot_w64((uint32_t)(threadIdx.x & 63) < (cap_left >> 2));
+            const wmask km = bal((uint32_t)(threadIdx.x & 63) < (cap_left >> 2));
             m0 &= km; m1 &= km; m2 &= km; m3 &= km;
             i0 &= km; i1 &= km; i2 &= km; i3 &= km;
-            void_mask = ~km;
+            *voided = ~km;
         }
     }
-    if (CHECK == 1) *voided = __builtin_amdgcn_inverse_ballot_w64(void_mask);
-    const bool l0 = __builtin_amdgcn_inverse_ballot_w64(m0), l1 = __builtin_amdgcn_inverse_ballot_w64(m1), l2 = __builtin_amdgcn_inverse_ballot_w64(m2), l3 = __builtin_amdgcn_inverse_ballot_w64(m3);
-#else
-    slab_quad_pruned<false>(a0, a1, a2, b0, b1, b2, o, inv, pinf(), t0, t1, t2, t3);
-    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-    // (one compare per operand, shared by the lane's predicate and the wave's mask: the mask is the AND of the two ballots)
-    // (t is an entry distance of finite operands or exactly +inf, never a NaN: the integer compare is the same test, and one the
-    // compiler does not rewrite differently for the predicate and for the ballot)
-    const bool h0 = __float_as_uint(t0) != 0x7f800000u, h1 = __float_as_uint(t1) != 0x7f800000u, h2 = __float_as_uint(t2) != 0x7f800000u, h3 = __float_as_uint(t3) != 0x7f800000u;
-    const bool n0 = r0 < 0, n1 = r1 < 0, n2 = r2 < 0, n3 = r3 < 0;
-#define CRT_LEAF_MASK(h_, n_) (__builtin_amdgcn_ballot_w64(h_) & __builtin_amdgcn_ballot_w64(n_))
-    uint32_t tail = lq_t + added;
-    unsigned long long m0 = CRT_LEAF_MASK(h0, n0), m1 = CRT_LEAF_MASK(h1, n1), m2 = CRT_LEAF_MASK(h2, n2), m3 = CRT_LEAF_MASK(h3, n3);
-#undef CRT_LEAF_MASK
-    bool l0 = h0 & n0, l1 = h1 & n1, l2 = h2 & n2, l3 = h3 & n3;
-    if (CHECK != 0) {
-        if ((uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3)) > cap_left) {
-            if (CHECK == 2) { *bailed = true; return false; }
-            // the lanes a quarter of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
-            const bool keep = (uint32_t)(threadIdx.x & 63) < (cap_left >> 2);
-            const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
-            m0 &= km; m1 &= km; m2 &= km; m3 &= km;
-            l0 = l0 & keep; l1 = l1 & keep; l2 = l2 & keep; l3 = l3 & keep;
-            t0 = keep ? t0 : inf; t1 = keep ? t1 : inf; t2 = keep ? t2 : inf; t3 = keep ? t3 : inf;
-            *voided = !keep;
-        }
-    }
-#endif
-    if (STATS && enable && !(CHECK == 1 && *voided)) tc.inner++;
-    leafq_push_all(S, l0, m0, ((uint32_t)r0 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l1, m1, ((uint32_t)r1 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l2, m2, ((uint32_t)r2 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, l3, m3, ((uint32_t)r3 & 0x7fffff00u) | id, tail);
+    const wmask EFF = CHECK == 1 ? EN & ~*voided : EN; // the lanes whose visit counts
+    if (STATS && lanes(EFF)) tc.inner++;
+    leafq_push_all(S, lanes(m0), m0, ((uint32_t)r0 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, lanes(m1), m1, ((uint32_t)r1 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, lanes(m2), m2, ((uint32_t)r2 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, lanes(m3), m3, ((uint32_t)r3 & 0x7fffff00u) | id, tail);
     added = tail - lq_t;
-    n_leaf = (l0 ? 1u : 0u) + (l1 ? 1u : 0u) + (l2 ? 1u : 0u) + (l3 ? 1u : 0u);
-#if CRT_X_BOOLMASK
-    any_leaf = __builtin_amdgcn_inverse_ballot_w64(m0 | m1 | m2 | m3);
-    t0 = __builtin_amdgcn_inverse_ballot_w64(i0) ? t0 : inf; t1 = __builtin_amdgcn_inverse_ballot_w64(i1) ? t1 : inf;
-    t2 = __builtin_amdgcn_inverse_ballot_w64(i2) ? t2 : inf; t3 = __builtin_amdgcn_inverse_ballot_w64(i3) ? t3 : inf;
-#else
-    any_leaf = l0 | l1 | l2 | l3;
-    t0 = n0 ? inf : t0; t1 = n1 ? inf : t1; t2 = n2 ? inf : t2; t3 = n3 ? inf : t3;
-#endif
-#define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
-#ifndef CRT_DEC_UNSORTED
-    CRT_CE(t0, r0, t1, r1) CRT_CE(t2, r2, t3, r3) CRT_CE(t0, r0, t2, r2)
-#endif
-#undef CRT_CE
-    const bool c0 = t0 < inf, c1 = t1 < inf, c2 = t2 < inf, c3 = t3 < inf;
-    const int l3_ = sp, l2_ = l3_ + (c3 ? 1 : 0), l1_ = l2_ + (c2 ? 1 : 0);
+    n_leaf = add_mask(add_mask(add_mask(add_mask(n_leaf, m0), m1), m2), m3);
+    any_leaf |= (m0 | m1) | (m2 | m3);
+    // The nearest inner child that is hit goes to the front, by a tournament (0,1)(2,3)(winners) on (hit, distance): b beats a iff b is hit and
+    // (a is not, or b is nearer).  Only the winner's distance is ever compared again, and "is hit" travels as a mask -- front = a | b, back = a & b --
+    // so an exchange is a compare, a select of the winner's distance and two selects of the refs (round 5: distances forced to +inf for the
+    // children that are not inner hits, five selects per exchange and a compare with +inf per child afterwards: 23 vector instructions, now 11).
+    // The order of the visits is the one of round 5: the result cannot depend on it (crt_trace.h), the any-hit rays' visit counts do.
+    const wmask S01 = i1 & (bal(t1 < t0) | ~i0), S23 = i3 & (bal(t3 < t2) | ~i2);
+    const float tA = lanes(S01) ? t1 : t0, tC = lanes(S23) ? t3 : t2;
+    const int rA = lanes(S01) ? r1 : r0, rB = lanes(S01) ? r0 : r1, rC = lanes(S23) ? r3 : r2, rD = lanes(S23) ? r2 : r3;
+    const wmask IA = i0 | i1, IB = i0 & i1, IC = i2 | i3, ID = i2 & i3;
+    const wmask S02 = IC & (bal(tC < tA) | ~IA);
+    const int rF = lanes(S02) ? rC : rA, rG = lanes(S02) ? rA : rC;
+    const wmask IF = IA | IC, IG = IA & IC;
+    // pushed: the loser of (2,3), then the loser of the final, then the loser of (0,1) -- which is popped first
+    const int l3_ = sp, l2_ = add_mask(l3_, ID), l1_ = add_mask(l2_, IG), sp_new = add_mask(l1_, IB);
     constexpr int LV = LDS::LV;
     typedef typename LDS::stk_t stk_t;
-    if (c3 & (l3_ < LV)) S.stk[l3_][id] = (stk_t)r3;
-    if (c2 & (l2_ < LV)) S.stk[l2_][id] = (stk_t)r2;
-    if (c1 & (l1_ < LV)) S.stk[l1_][id] = (stk_t)r1;
-    const int sp_new = l1_ + (c1 ? 1 : 0);
-    if (__builtin_amdgcn_ballot_w64((sp_new > l3_) & (sp_new > LV))) {
-        if (c3 & (l3_ >= LV)) M.spill[(size_t)(l3_ - LV) * M.M.spill_stride + g] = r3;
-        if (c2 & (l2_ >= LV)) M.spill[(size_t)(l2_ - LV) * M.M.spill_stride + g] = r2;
-        if (c1 & (l1_ >= LV)) M.spill[(size_t)(l1_ - LV) * M.M.spill_stride + g] = r1;
+    if (lanes(ID & bal(l3_ < LV))) S.stk[l3_][id] = (stk_t)rD;
+    if (lanes(IG & bal(l2_ < LV))) S.stk[l2_][id] = (stk_t)rG;
+    if (lanes(IB & bal(l1_ < LV))) S.stk[l1_][id] = (stk_t)rB;
+    if (bal((sp_new > l3_) & (sp_new > LV))) {
+        if (lanes(ID & bal(l3_ >= LV))) M.spill[(size_t)(l3_ - LV) * M.M.spill_stride + g] = rD;
+        if (lanes(IG & bal(l2_ >= LV))) M.spill[(size_t)(l2_ - LV) * M.M.spill_stride + g] = rG;
+        if (lanes(IB & bal(l1_ >= LV))) M.spill[(size_t)(l1_ - LV) * M.M.spill_stride + g] = rB;
     }
-    sp = sp_new;
-    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
+    if (STATS && (uint32_t)sp_new > max_sp) max_sp = (uint32_t)sp_new;
     // the nearest inner child next; without one (nothing was pushed either: the top is the one read above) the stack's top, or the end
-    const bool pop = !c0 & (sp > 0);
-    const bool over = !c0 & (sp == 0);
-    ref = c0 ? r0 : top;
-    sp -= pop ? 1 : 0;
-    if (__builtin_amdgcn_ballot_w64(pop & (sp >= LV))) {
-        if (pop & (sp >= LV)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
+    const wmask NF = EFF & ~IF;
+    const wmask POP = NF & bal(sp_new > 0);
+    const wmask OVER = NF & ~POP;
+    const int nref = lanes(IF) ? rF : top;
+    ref = lanes(IF | POP) ? nref : ref;
+    sp = sub_mask(sp_new, POP);
+    const wmask DEEP = POP & bal(sp >= LV); // (of the new depth -- the carry instruction's own result: the compiler shares a compare of sp_new with the push block's and sends it through a vector register)
+    if (DEEP) {
+        if (lanes(DEEP)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
     }
-    return over;
+    return OVER;
 }
-
-#if CRT_WIDE != 4
-// ---- experiment builds (-DCRT_WIDE=6 / 8, round 5): the decoupled inner step at a node of CRT_WIDE children ----
-// Children 0..3 are a quad in the layout of a nodes4 node; children 4.. a second quad (CRT_WIDE 8) or a pair (CRT_WIDE 6: per axis one
-// float4 (lo c4, lo c5, hi c4, hi c5), the near / far halves picked by the load address as for the quads).  Everything else is
-// inner4_step_dec with CRT_WIDE in place of four: one accept mask per child, CRT_WIDE appends to the leaf queue, the nearest inner child
-// to the front by a tournament (CRT_WIDE - 1 exchanges), the others pushed.
-__device__ __forceinline__ void slab_pair_hits(const float2 nx, const float2 fx, const float2 ny, const float2 fy, const float2 nz, const float2 fz,
-                                               const F3 o, const F3 inv, float& e0, float& e1, unsigned long long& h0, unsigned long long& h1)
-{
-    // (scalar arithmetic: a subtraction and a multiplication issue in 2.5 cycles each, a packed one in 4.4 -- for one pair the packed form buys
-    // nothing, and the compiler built its broadcast operands through scratch memory)
-    const float nax = (nx.x - o.x) * inv.x, nay = (nx.y - o.x) * inv.x, nbx = (ny.x - o.y) * inv.y, nby = (ny.y - o.y) * inv.y, ncx = (nz.x - o.z) * inv.z, ncy = (nz.y - o.z) * inv.z;
-    const float fax = (fx.x - o.x) * inv.x, fay = (fx.y - o.x) * inv.x, fbx = (fy.x - o.y) * inv.y, fby = (fy.y - o.y) * inv.y, fcx = (fz.x - o.z) * inv.z, fcy = (fz.y - o.z) * inv.z;
-    e0 = fmax3(nax, nbx, ncx); e1 = fmax3(nay, nby, ncy);
-    const float x0 = fmin3(fax, fbx, fcx), x1 = fmin3(fay, fby, fcy);
-    h0 = __builtin_amdgcn_ballot_w64(e0 <= x0 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x0 >= 0);
-    h1 = __builtin_amdgcn_ballot_w64(e1 <= x1 + CRT_EPSILON) & __builtin_amdgcn_ballot_w64(x1 >= 0);
-}
-template <bool STATS, class LDS, int CHECK = 0>
-__device__ __forceinline__ bool innerw_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 o, const F3 dir,
-                                                int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, bool& any_leaf,
-                                                uint32_t& n_leaf, const bool enable, const uint32_t cap_left = 0, bool* bailed = nullptr, bool* voided = nullptr)
-{
-    constexpr int W = CRT_WIDE;
-    constexpr uint32_t NODE_BYTES = W == 8 ? 256u : 192u;
-    const char* nb = (const char*)sc.nodesw;
-    const uint32_t noff = enable ? (uint32_t)ref * NODE_BYTES : sc.emptyw_off;
-    const uint32_t sx = (__float_as_uint(dir.x) >> 27) & 16u, sy = (__float_as_uint(dir.y) >> 27) & 16u, sz = (__float_as_uint(dir.z) >> 27) & 16u;
-    const uint32_t ox = noff + sx, oy = noff + sy, oz = noff + sz;
-    const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
-    const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
-    const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
-    const float4 rfa = *(const float4*)((nb + noff) + 112);
-    float t[W];
-    int r[W];
-    unsigned long long H[W];
-    const int top = stack_top_ahead(S, id, sp, LDS::LV);
-    F3 inv = inv3_exact(dir);
-    asm volatile("" : "+v"(inv.x), "+v"(inv.y), "+v"(inv.z)); // (three scalars: packed into a vector the compiler extracts pairs of it through scratch memory)
-    const float inf = pinf();
-    slab_quad_hits(a0, a1, a2, b0, b1, b2, o, inv, t[0], t[1], t[2], t[3], H[0], H[1], H[2], H[3]);
-    r[0] = __float_as_int(rfa.x); r[1] = __float_as_int(rfa.y); r[2] = __float_as_int(rfa.z); r[3] = __float_as_int(rfa.w);
-    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
-    // (the second half is fetched once the first has been consumed: fourteen loads in flight at once do not fit the registers of a wave
-    // that runs four to a SIMD -- the compiler then shuffles the ray's own values through scratch memory)
-    if constexpr (W == 8) {
-        const float4 c0 = *(const float4*)((nb + ox) + 128), c1 = *(const float4*)((nb + (ox ^ 16u)) + 128);
-        const float4 c2 = *(const float4*)((nb + oy) + 160), d0 = *(const float4*)((nb + (oy ^ 16u)) + 160);
-        const float4 d1 = *(const float4*)((nb + oz) + 192), d2 = *(const float4*)((nb + (oz ^ 16u)) + 192);
-        const float4 rfb = *(const float4*)((nb + noff) + 240);
-        slab_quad_hits(c0, c1, c2, d0, d1, d2, o, inv, t[4], t[5], t[6], t[7], H[4], H[5], H[6], H[7]);
-        r[4] = __float_as_int(rfb.x); r[5] = __float_as_int(rfb.y); r[6] = __float_as_int(rfb.z); r[7] = __float_as_int(rfb.w);
-        asm volatile("" : "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
-    } else {
-        const uint32_t px = noff + (sx >> 1), py = noff + (sy >> 1), pz = noff + (sz >> 1); // + 8: the hi half of the row is the near one
-        const float2 p0 = *(const float2*)((nb + px) + 128), q0 = *(const float2*)((nb + (px ^ 8u)) + 128);
-        const float2 p1 = *(const float2*)((nb + py) + 144), q1 = *(const float2*)((nb + (py ^ 8u)) + 144);
-        const float2 p2 = *(const float2*)((nb + pz) + 160), q2 = *(const float2*)((nb + (pz ^ 8u)) + 160);
-        const float2 rfb = *(const float2*)((nb + noff) + 176);
-        slab_pair_hits(p0, q0, p1, q1, p2, q2, o, inv, t[4], t[5], H[4], H[5]);
-        r[4] = __float_as_int(rfb.x); r[5] = __float_as_int(rfb.y);
-        asm volatile("" : "+v"(t[4]), "+v"(t[5]));
-    }
-    uint32_t tail = lq_t + added;
-    unsigned long long m[W], ii[W];
-    uint32_t n_entries = 0;
-#pragma unroll
-    for (int i = 0; i < W; i++) {
-        const unsigned long long N = __builtin_amdgcn_ballot_w64(r[i] < 0);
-        m[i] = H[i] & N; ii[i] = H[i] & ~N;
-        n_entries += (uint32_t)__popcll(m[i]);
-    }
-    unsigned long long void_mask = 0ull;
-    if (CHECK != 0) {
-        if (n_entries > cap_left) {
-            if (CHECK == 2) { *bailed = true; return false; }
-            // the lanes a W-th of the free entries has room for stay (lane numbers: the batch's lanes are 0 .. take - 1)
-            const unsigned long long km = __builtin_amdgcn_ballot_w64((uint32_t)(threadIdx.x & 63) < cap_left / (uint32_t)W);
-#pragma unroll
-            for (int i = 0; i < W; i++) { m[i] &= km; ii[i] &= km; }
-            void_mask = ~km;
-        }
-    }
-    if (CHECK == 1) *voided = __builtin_amdgcn_inverse_ballot_w64(void_mask);
-    if (STATS && enable && !(CHECK == 1 && *voided)) tc.inner++;
-    n_leaf = 0;
-    unsigned long long many = 0ull;
-#pragma unroll
-    for (int i = 0; i < W; i++) {
-        const bool l = __builtin_amdgcn_inverse_ballot_w64(m[i]);
-        leafq_push_all(S, l, m[i], ((uint32_t)r[i] & 0x7fffff00u) | id, tail);
-        n_leaf += l ? 1u : 0u;
-        many |= m[i];
-        t[i] = __builtin_amdgcn_inverse_ballot_w64(ii[i]) ? t[i] : inf;
-    }
-    added = tail - lq_t;
-    any_leaf = __builtin_amdgcn_inverse_ballot_w64(many);
-#define CRT_CE(ta, ra, tb, rb) { const bool sw_ = tb < ta; const float tt_ = sw_ ? tb : ta; tb = sw_ ? ta : tb; ta = tt_; const int rr_ = sw_ ? rb : ra; rb = sw_ ? ra : rb; ra = rr_; }
-    // the nearest inner child to the front: a tournament
-#pragma unroll
-    for (int s_ = 1; s_ < W; s_ *= 2)
-#pragma unroll
-        for (int i = 0; i + s_ < W; i += 2 * s_) CRT_CE(t[i], r[i], t[i + s_], r[i + s_])
-#undef CRT_CE
-    constexpr int LV = LDS::LV;
-    typedef typename LDS::stk_t stk_t;
-    bool c[W];
-    int lvl[W];
-    int run = sp;
-#pragma unroll
-    for (int k = W - 1; k >= 1; k--) {
-        c[k] = t[k] < inf;
-        lvl[k] = run;
-        if (c[k] & (run < LV)) S.stk[run][id] = (stk_t)r[k];
-        run += c[k] ? 1 : 0;
-    }
-    const int sp_new = run;
-    if (__builtin_amdgcn_ballot_w64((sp_new > sp) & (sp_new > LV))) {
-#pragma unroll
-        for (int k = W - 1; k >= 1; k--)
-            if (c[k] & (lvl[k] >= LV)) M.spill[(size_t)(lvl[k] - LV) * M.M.spill_stride + g] = r[k];
-    }
-    sp = sp_new;
-    if (STATS && (uint32_t)sp > max_sp) max_sp = (uint32_t)sp;
-    const bool c0_ = t[0] < inf;
-    const bool pop = !c0_ & (sp > 0);
-    const bool over = !c0_ & (sp == 0);
-    ref = c0_ ? r[0] : top;
-    sp -= pop ? 1 : 0;
-    if (__builtin_amdgcn_ballot_w64(pop & (sp >= LV))) {
-        if (pop & (sp >= LV)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
-    }
-    return over;
-}
-#define inner_step_dec_x innerw_step_dec
-#else
-#define inner_step_dec_x inner4_step_dec
-#endif
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
 // visit order, no pruning) or, for the handful of FAST rays with non-finite operands, reference arithmetic on that topology
@@ -1357,21 +1221,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             constexpr bool MAY_EXACT = decltype(may_exact_)::value;
             if constexpr (DEC) {
             // ---- inner-node step: the child boxes; leaf children that are hit -> queue entries; nearest inner child next ----
-            // The whole step, the appends to the leaf queue and to the inner ring included, runs under the mask of the batch's lanes
-            // (a ballot there sees those lanes only); what the appends add to the wave-uniform cursors comes out of the region in a
-            // vector register of lane 0, which is always one of them.
+            // All 64 lanes run the step (round 6): a lane without a ray of the batch (ON is the batch) steps at the EMPTY node like every other
+            // lane that sits the visit out, so there is no divergent region around the step, every predicate is a wave mask and every
+            // wave-uniform count -- queue entries appended, rays re-queued -- stays in a scalar register (until round 5 they left the region
+            // in a vector register, through v_readfirstlane).  Stores and LDS atomics are predicated by `lanes(mask)`.
             // (the batch is not cut to the quarter of the free queue entries that could take four entries per ray: the entries of a visit
             // are counted before any is written, and should they not fit -- rarely: a ray adds 0.8 on average -- the lanes beyond that quarter are
             // taken out of the visit again and queued as they came, inner4_step_dec.  Batches 57 -> 62 rays: C2 80.4 -> 79.5 ms, veach 80.4 -> 79.2)
             const int take = min(64, qn[PH3_INNER]);
             if (STATS) { dg_b[PH3_INNER]++; dg_l[PH3_INNER] += (uint32_t)take; }
-            const bool on = lane < take;
-            const uint32_t id = S.rq(PH3_INNER)[ring_wrap<QCAP>(RQ_POP_BASE(PH3_INNER, take) + (uint32_t)lane)];
+            const wmask ON = bal(lane < take);
+            // (a lane beyond the batch reads an entry of the ring that is not part of it -- a ray id of this pool all the same, or the
+            // ring's initial bytes: the id is forced into the pool)
+            const uint32_t id_raw = S.rq(PH3_INNER)[ring_wrap<QCAP>(RQ_POP_BASE(PH3_INNER, take) + (uint32_t)lane)];
             RQ_POP_ADV(PH3_INNER, take)
+            const uint32_t id = lanes(ON) ? id_raw : 0u;
             const uint32_t g = base + id;
-            uint32_t xfer = 0;            // entries appended to the leaf queue | rays re-queued << 16 | rays of the reference-arithmetic path that ended << 24
             uint32_t nph = PH3_NONE;      // a ray that is complete (its walk is over and none of its entries is in flight): where it goes
-            if (on) {
+            uint32_t added = 0;           // entries of the batch so far (wave-uniform)
+            wmask DONE, EXQ = 0ull;
+            {
                 const float4 qa = S.A[id], qb = S.B[id];
                 const uint32_t qd = S.D[id];
                 const uint32_t blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1379,28 +1248,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const F3 o = f3(qa.x, qa.y, qa.z), dir = f3(qb.x, qb.y, qb.z);
                 int sp = (int)(qd & 0xffu);
                 // an any-hit ray that has its answer looks no further (entries of it still in the queue are tested and change nothing)
-                bool done = (qd & RF_ANYHIT) != 0 && blo != 0u;
-                const bool go = !done;
-                const bool ex = MAY_EXACT && (qd & RF_EXACT) != 0;
-                uint32_t added = 0, n_leaf = 0; // entries of the batch so far (wave-uniform); entries of this ray from its 4-wide step
-                bool any_leaf = false;
+                const wmask D0 = bal((qd & RF_ANYHIT) != 0) & bal(blo != 0u) & ON;
+                const wmask GO = ON & ~D0;
+                const wmask EX = MAY_EXACT ? bal((qd & RF_EXACT) != 0) : 0ull;
+                DONE = D0;
+                int n_leaf = 0;           // entries of this ray from its 4-wide visits
+                wmask ANY = 0ull;         // rays that appended an entry in this step
                 {
-                    // (a lane that does not take the step -- see inner4_step_dec -- keeps its node, depth and `done`)
-                    const bool en = go && !ex;
-                    int ref4 = ref, sp4 = sp;
-                    bool voided = false;
+                    wmask VOID = 0ull;
+                    RayPk R;
+                    R.oxy = v2(qa.x, qa.y); R.oz.x = qa.z;
                     // (free entries, saturating: the scheduler drains the queue from LEAFQ_FIRST entries on and a step adds at most what is
                     // free, so the difference cannot be negative -- but a wrapped unsigned here would switch the overflow check off for good)
                     const uint32_t lq_used = (lq_t - lq_h) + (MAY_EXACT ? 64u : 0u);
                     const uint32_t lq_free = lq_used < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used : 0u;
-                    const bool done4 = inner_step_dec_x<STATS, LDS3, 1>(sc, S, M3, id, g, o, dir, ref4, sp4, tc, max_sp, lq_t, added, any_leaf, n_leaf, en,
-                                                                       lq_free, nullptr, &voided);
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
-                    {   // (selects, not a branch around three moves: 12 scalar instructions fewer per step for 10 vector ones more; measured level, round 5)
-                        const bool take4 = en & !voided;
-                        ref = take4 ? ref4 : ref; sp = take4 ? sp4 : sp; done = take4 ? done4 : done;
-                    }
-                    if (STATS && en && voided) dg_ov[0]++;
+                    DONE |= inner4_step_dec<STATS, LDS3, 1>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, GO & ~EX, lq_free, nullptr, &VOID);
+                    if (STATS && lanes(GO & ~EX & VOID)) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
                     // least VISIT2_MIN lanes go on; its leaf entries are counted before anything is written, and if the queue cannot take
@@ -1411,62 +1275,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
 #define CRT_VISIT2_MIN 44
 #endif
                         constexpr int VISIT2_MIN = CRT_VISIT2_MIN;
-                        const bool en2 = go && !done;
-                        if ((int)__popcll(__builtin_amdgcn_ballot_w64(en2)) >= VISIT2_MIN) {
+                        const wmask EN2 = ON & ~DONE;
+                        if ((int)__popcll(EN2) >= VISIT2_MIN) {
                             const uint32_t lq_used2 = (lq_t + added) - lq_h;
                             const uint32_t cap_left = lq_used2 < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used2 : 0u;
-                            bool bailed = false, any2 = false;
-                            uint32_t n2 = 0;
-                            int ref5 = ref, sp5 = sp;
-                            const bool done5 = inner_step_dec_x<STATS, LDS3, 2>(sc, S, M3, id, g, o, dir, ref5, sp5, tc, max_sp, lq_t, added, any2, n2, en2, cap_left, &bailed);
-                            {
-                                const bool take5 = en2 & !bailed;
-                                ref = take5 ? ref5 : ref; sp = take5 ? sp5 : sp; done = take5 ? done5 : done;
-                                n_leaf += take5 ? n2 : 0u; any_leaf = any_leaf | (take5 & any2);
-                            }
-                            if (STATS && bailed && en2) dg_ov[1]++;
+                            bool bailed = false;
+                            DONE |= inner4_step_dec<STATS, LDS3, 2>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN2, cap_left, &bailed);
+                            if (STATS && bailed && lanes(EN2)) dg_ov[1]++;
                         }
                     }
                 }
                 if (MAY_EXACT) {
-                    if (__builtin_amdgcn_ballot_w64(go && ex)) { // reference arithmetic on the reference topology, one thing per visit:
-                        const bool lf = go && ex && ref < 0;     // a leaf ref becomes a queue entry, an inner node is stepped
-                        leafq_push(S, id, lf, __builtin_amdgcn_ballot_w64(lf), ((uint32_t)~ref << 8) | id, lq_t, added);
-                        if (go && ex) {
-                            if (lf) {
-                                any_leaf = true;
-                                done = stack_pop(S, M3, id, g, sp, ref, lds_levels<LDS3>(true));
-                            } else {
-                                done = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv3_exact(dir), dir, pinf(), ref, sp, tc, max_sp);
-                            }
+                    const wmask GX = GO & EX;
+                    if (GX) { // reference arithmetic on the reference topology, one thing per visit: a leaf ref becomes a queue entry, an inner node is stepped
+                        const wmask LF = GX & bal(ref < 0);
+                        leafq_push(S, id, lanes(LF), LF, ((uint32_t)~ref << 8) | id, lq_t, added);
+                        bool dn = false;
+                        if (lanes(GX)) {
+                            if (lanes(LF)) dn = stack_pop(S, M3, id, g, sp, ref, lds_levels<LDS3>(true));
+                            else dn = inner2_step<0, STATS>(sc, S, M3, id, g, o, inv3_exact(dir), dir, pinf(), ref, sp, tc, max_sp);
                         }
+                        ANY |= LF;
+                        DONE |= bal(dn) & GX;
                     }
+                    EXQ = DONE & EX; // rays of the reference-arithmetic path whose walk ended
                 }
                 // the record: node, stack depth, "the walk is over" -- the count of entries in flight in between is touched by atomics only
                 // (leafq_push above: those additions are in LDS before this one, same wave, in order)
-                if (STATS) { for (int k = 0; k < 6; k++) dg_sp[k] += sp > k + 1 ? 1u : 0u; }
-                S.B[id].w = __int_as_float(ref);
-                __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (done ? RD_FIN : 0u) + (n_leaf << RD_PEND_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const bool comp = done & !any_leaf & ((qd & RD_PEND_MASK) == 0u);
-                if (STATS && comp && blo != 0u) tc.hits++;
-                if (__builtin_amdgcn_ballot_w64(comp)) nph = comp ? route_complete<QUERY>(qd, blo != 0u) : nph;
-                // re-queue the rays that go on
-                const unsigned long long mc = __builtin_amdgcn_ballot_w64(!done);
-                if (mc) {
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mc >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mc, RQ_PUSH_BASE(PH3_INNER)));
-                    if (!done) S.rq(PH3_INNER)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
+                if (STATS) { for (int k = 0; k < 6; k++) dg_sp[k] += (lanes(ON) && sp > k + 1) ? 1u : 0u; }
+                if (lanes(ON)) {
+                    S.B[id].w = __int_as_float(ref);
+                    __hip_atomic_fetch_add(&S.D[id], (uint32_t)sp - (qd & 0xffu) + (lanes(DONE) ? RD_FIN : 0u) + ((uint32_t)n_leaf << RD_PEND_SHIFT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                xfer = added | ((uint32_t)__popcll(mc) << 16);
-                if (MAY_EXACT) xfer |= (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(done && (qd & RF_EXACT) != 0)) << 24;
+                const wmask COMP = DONE & ~ANY & bal((qd & RD_PEND_MASK) == 0u);
+                if (STATS && lanes(COMP) && blo != 0u) tc.hits++;
+                if (COMP) nph = lanes(COMP) ? route_complete<QUERY>(qd, blo != 0u) : nph;
             }
-            xfer = (uint32_t)__builtin_amdgcn_readfirstlane((int)xfer);
-            lq_t += xfer & 0xffffu;
-            {
-                const int c = (int)((xfer >> 16) & 0xffu);
+            // re-queue the rays that go on
+            const wmask MC = ON & ~DONE;
+            if (MC) {
+                const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(MC >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)MC, RQ_PUSH_BASE(PH3_INNER)));
+                if (lanes(MC)) S.rq(PH3_INNER)[ring_wrap<QCAP>(slot)] = (uint8_t)id;
+                const int c = (int)__popcll(MC);
                 RQ_PUSH_ADV(PH3_INNER, c)
             }
-            if (MAY_EXACT) n_exact -= (int)(xfer >> 24);
-            if (__builtin_amdgcn_ballot_w64(nph != PH3_NONE)) {
+            lq_t += added;
+            if (MAY_EXACT) n_exact -= (int)__popcll(EXQ);
+            if (bal(nph != PH3_NONE)) {
                 PUSH_ONE(PH3_LA, nph == PH3_LA) PUSH_ONE(PH3_LB, nph == PH3_LB) PUSH_ONE(PH3_LC, nph == PH3_LC)
             }
             }
@@ -1474,15 +1329,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
         auto leaf_arm_dec = [&]() __attribute__((always_inline)) {
             if constexpr (DEC) {
             // ---- leaf step: 64 entries of the queue, the record's two triangles in one packed computation ----
+            // All 64 lanes run it (round 6, as the inner step): a lane beyond the batch takes entry 0 of record 0 -- valid addresses -- and its
+            // result is dropped: the minimum and the count of entries in flight are touched under `lanes(ON)` only.
             const int take = min(64, (int)(lq_t - lq_h));
             if (STATS) { dg_b[PH3_LEAF]++; dg_l[PH3_LEAF] += (uint32_t)take; }
-            const bool on = lane < take;
-            const uint32_t item = S.leafq[(lq_h + (uint32_t)lane) & (uint32_t)(LEAFQ_CAP - 1)];
+            const wmask ON = bal(lane < take);
+            const uint32_t item_raw = S.leafq[(lq_h + (uint32_t)lane) & (uint32_t)(LEAFQ_CAP - 1)];
             lq_h += (uint32_t)take;
+            const uint32_t item = lanes(ON) ? item_raw : 0u;
             const uint32_t id = item & 0xffu;
-            bool comp = false;
-            uint32_t t_flags = 0, blo = 0;
-            if (on) {
+            wmask COMP = 0ull;
+            uint32_t t_flags = 0;
+            {
                 const float4 qa = S.A[id], qb = S.B[id];
                 const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
                 const float Tl = qa.w;
@@ -1503,7 +1361,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     bool a0, a1;
                     float t0, t1;
                     tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
-                    if (STATS) { tc.tests += two ? 2u : 1u; }
+                    if (STATS && lanes(ON)) { tc.tests += two ? 2u : 1u; }
                     // (Tl - t > EPSILON: the visibility test of an any-hit ray, Render.cuh:19-27; always true for Tl = +inf and a finite t,
                     // false for t = +inf, which the reference's t < best.t rejects as well)
                     const bool b0 = a0 & (Tl - t0 > CRT_EPSILON);
@@ -1515,20 +1373,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     bt = up ? ct : bt; bi = up ? ci : bi; have = have | up;
                     left -= 2;
                 }
-                if (STATS) tc.leaf++;
-                // across leaves: the smaller distance, among equal ones the larger leaf start (crt_trace.h) = the larger triangle index, as
-                // the leaves own disjoint ascending ranges -- one 64-bit minimum over (bits(t), ~triangle); t > EPSILON > 0, so its bits order as it does
-                if (__builtin_amdgcn_ballot_w64(have)) {
+                if (STATS && lanes(ON)) tc.leaf++;
+                if (lanes(ON)) {
+                    // across leaves: the smaller distance, among equal ones the larger leaf start (crt_trace.h) = the larger triangle index, as
+                    // the leaves own disjoint ascending ranges -- one 64-bit minimum over (bits(t), ~triangle); t > EPSILON > 0, so its bits order as it does
                     if (have) __hip_atomic_fetch_min(&S.best[id], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)(uint32_t)~bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t od = __hip_atomic_fetch_sub(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    t_flags = od;
                 }
-                const uint32_t od = __hip_atomic_fetch_sub(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                comp = (od & (RD_PEND_MASK | RD_FIN)) == ((1u << RD_PEND_SHIFT) | RD_FIN); // the last entry of a ray whose walk is over
-                t_flags = od;
+                COMP = bal((t_flags & (RD_PEND_MASK | RD_FIN)) == ((1u << RD_PEND_SHIFT) | RD_FIN)); // the last entry of a ray whose walk is over (t_flags is 0 beyond the batch)
             }
-            if (__builtin_amdgcn_ballot_w64(comp)) {
-                if (comp) blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (STATS && comp && blo != 0u) tc.hits++;
-                const uint32_t nph = comp ? route_complete<QUERY>(t_flags, blo != 0u) : (uint32_t)PH3_NONE;
+            if (COMP) {
+                uint32_t blo = 0;
+                if (lanes(COMP)) blo = (uint32_t)__hip_atomic_load(&S.best[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (STATS && lanes(COMP) && blo != 0u) tc.hits++;
+                const uint32_t nph = lanes(COMP) ? route_complete<QUERY>(t_flags, blo != 0u) : (uint32_t)PH3_NONE;
                 PUSH_ONE(PH3_LA, nph == PH3_LA) PUSH_ONE(PH3_LB, nph == PH3_LB) PUSH_ONE(PH3_LC, nph == PH3_LC)
             }
             }

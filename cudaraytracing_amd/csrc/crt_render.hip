@@ -21,11 +21,6 @@ struct crt_scene {
     int device = 0;
     DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4;
     int depth4 = 1; // depth of the 4-wide tree
-#if CRT_WIDE != 4
-    DevBuf<float4> nodesw; // the CRT_WIDE-wide tree of the decoupled-leaves kernels (experiment builds)
-    int depthw = 1;
-    uint32_t n_nodesw = 0;
-#endif
     bool ref16_ok = false; // refs of the 4-wide tree and of the leaf records fit 16 bits (k_mega3's 16-bit stack layout)
     bool ref16_inner_ok = false; // refs of the 4-wide tree alone fit 16 bits (decoupled leaves: the stack holds inner nodes only)
     bool dec_ok = false;         // leaf records fit the 24 bits of a leaf-queue entry
@@ -1028,141 +1023,11 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->nodes4.upload(nodes4);
         sc->dev.nodes4 = sc->nodes4.p;
         sc->dev.root4 = root4;
-#if CRT_WIDE != 4
-        // ---- the same collapse for CRT_WIDE children per node (experiment builds, round 5: VERDICT r04 item 1a): the tree the decoupled-leaves
-        //      kernels walk instead of nodes4.  Layout: quad A = children 0..3 exactly as a nodes4 node (128 B); then, CRT_WIDE 8: quad B =
-        //      children 4..7 in the same form (256 B per node); CRT_WIDE 6: a pair block of 64 B -- per axis one float4 (lo c4, lo c5, hi c4,
-        //      hi c5), then (dec ref 4, dec ref 5, -, -) (192 B per node).  Same dynamic programme: minimum summed area of the wide nodes.
-        {
-            constexpr int W = CRT_WIDE;
-            static_assert(W == 6 || W == 8, "CRT_WIDE: 4 (default), 6 or 8");
-            constexpr int STRIDE4 = W == 8 ? 16 : 12; // float4 per node
-            std::vector<float4> nodesw;
-            int32_t rootw = ref3(root_fast);
-            int depthw = 1;
-            const float pinf_ = std::numeric_limits<float>::infinity();
-            const int32_t er_i = ~0x7ffffff0;
-            auto dref = [](int32_t r) -> int32_t { return r >= 0 ? r : (int32_t)(0x80000000u | (((uint32_t)~r & 0x7fffffu) << 8)); };
-            struct ChildW { float lo[3], hi[3]; int32_t ref; };
-            auto children_w = [&](int32_t q, ChildW out[2]) {
-                const float4 n0 = nodes3[q * 4ull], n1 = nodes3[q * 4ull + 1], n2 = nodes3[q * 4ull + 2], n3 = nodes3[q * 4ull + 3];
-                out[0] = ChildW{{n0.x, n0.z, n1.x}, {n1.z, n2.x, n2.z}, 0};
-                out[1] = ChildW{{n0.y, n0.w, n1.y}, {n1.w, n2.y, n2.w}, 0};
-                std::memcpy(&out[0].ref, &n3.x, 4); std::memcpy(&out[1].ref, &n3.y, 4);
-            };
-            auto write_node = [&](size_t slot, const std::vector<ChildW>& ch, const std::vector<int32_t>& refs) {
-                float lo[8][3], hi[8][3]; int32_t rr[8];
-                for (int i = 0; i < 8; i++) {
-                    if (i < (int)ch.size()) { for (int a = 0; a < 3; a++) { lo[i][a] = ch[i].lo[a]; hi[i][a] = ch[i].hi[a]; } rr[i] = refs[i]; }
-                    else { for (int a = 0; a < 3; a++) { lo[i][a] = pinf_; hi[i][a] = -pinf_; } rr[i] = er_i; }
-                }
-                float4* o = &nodesw[slot * STRIDE4];
-                for (int a = 0; a < 3; a++) { o[2 * a] = make_float4(lo[0][a], lo[1][a], lo[2][a], lo[3][a]); o[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]); }
-                o[6] = make_float4(as_float(rr[0]), as_float(rr[1]), as_float(rr[2]), as_float(rr[3]));
-                o[7] = make_float4(as_float(dref(rr[0])), as_float(dref(rr[1])), as_float(dref(rr[2])), as_float(dref(rr[3])));
-                if (W == 8) {
-                    for (int a = 0; a < 3; a++) { o[8 + 2 * a] = make_float4(lo[4][a], lo[5][a], lo[6][a], lo[7][a]); o[8 + 2 * a + 1] = make_float4(hi[4][a], hi[5][a], hi[6][a], hi[7][a]); }
-                    o[14] = make_float4(as_float(rr[4]), as_float(rr[5]), as_float(rr[6]), as_float(rr[7]));
-                    o[15] = make_float4(as_float(dref(rr[4])), as_float(dref(rr[5])), as_float(dref(rr[6])), as_float(dref(rr[7])));
-                } else {
-                    for (int a = 0; a < 3; a++) o[8 + a] = make_float4(lo[4][a], lo[5][a], hi[4][a], hi[5][a]);
-                    o[11] = make_float4(as_float(dref(rr[4])), as_float(dref(rr[5])), as_float(er_i), as_float(er_i));
-                }
-            };
-            if (rootw >= 0) {
-                const size_t A3 = nodes3.size() / 4;
-                std::vector<double> Dv(A3 * (W - 1), 0.0);
-                std::vector<uint8_t> choice(A3 * (W - 1), 0), kw(A3, 1);
-                auto Dof = [&](int32_t c, int j) { return c < 0 ? 0.0 : Dv[(size_t)c * (W - 1) + (j - 1)]; };
-                auto areaw = [](const ChildW& c) {
-                    const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
-                    return dx * dy + dy * dz + dz * dx;
-                };
-                struct Fr { int32_t q; double area; int state; };
-                std::vector<Fr> st;
-                st.push_back(Fr{rootw, 0.0, 0});
-                while (!st.empty()) {
-                    Fr f = st.back();
-                    ChildW two[2];
-                    children_w(f.q, two);
-                    if (f.state == 0) {
-                        st.back().state = 1;
-                        for (int i = 0; i < 2; i++) if (two[i].ref >= 0) st.push_back(Fr{two[i].ref, areaw(two[i]), 0});
-                        continue;
-                    }
-                    st.pop_back();
-                    double best = 0.0; int bk = 1;
-                    for (int k = 1; k <= W - 1; k++) { const double v = Dof(two[0].ref, k) + Dof(two[1].ref, W - k); if (k == 1 || v < best) { best = v; bk = k; } }
-                    kw[(size_t)f.q] = (uint8_t)bk;
-                    double* D = &Dv[(size_t)f.q * (W - 1)];
-                    uint8_t* C = &choice[(size_t)f.q * (W - 1)];
-                    D[0] = f.area + best;
-                    for (int j = 2; j <= W - 1; j++) {
-                        D[j - 1] = D[j - 2]; C[j - 1] = 0;
-                        for (int k = 1; k <= j - 1; k++) { const double v = Dof(two[0].ref, k) + Dof(two[1].ref, j - k); if (v < D[j - 1]) { D[j - 1] = v; C[j - 1] = (uint8_t)k; } }
-                    }
-                }
-                std::vector<ChildW> cover;
-                struct Ex { ChildW c; int j; };
-                auto expand = [&](const ChildW& c0, int j0) {
-                    std::vector<Ex> ex;
-                    ex.push_back(Ex{c0, j0});
-                    while (!ex.empty()) {
-                        Ex e = ex.back(); ex.pop_back();
-                        if (e.c.ref < 0 || e.j == 1) { cover.push_back(e.c); continue; }
-                        const int ch = choice[(size_t)e.c.ref * (W - 1) + (e.j - 1)];
-                        if (ch == 0) { ex.push_back(Ex{e.c, e.j - 1}); continue; }
-                        ChildW two[2];
-                        children_w(e.c.ref, two);
-                        ex.push_back(Ex{two[1], e.j - ch});
-                        ex.push_back(Ex{two[0], ch});
-                    }
-                };
-                struct Todo { int32_t node2; int32_t slot; int depth; };
-                std::vector<Todo> todo;
-                nodesw.resize(STRIDE4);
-                todo.push_back(Todo{rootw, 0, 1});
-                rootw = 0;
-                for (size_t t = 0; t < todo.size(); t++) {
-                    const Todo cur = todo[t];
-                    depthw = std::max(depthw, cur.depth + 1);
-                    ChildW two[2];
-                    children_w(cur.node2, two);
-                    cover.clear();
-                    expand(two[0], kw[(size_t)cur.node2]);
-                    expand(two[1], W - kw[(size_t)cur.node2]);
-                    std::vector<int32_t> refs(cover.size());
-                    for (size_t i = 0; i < cover.size(); i++) {
-                        if (cover[i].ref >= 0) {
-                            refs[i] = (int32_t)(nodesw.size() / STRIDE4);
-                            nodesw.resize(nodesw.size() + STRIDE4);
-                            todo.push_back(Todo{cover[i].ref, refs[i], cur.depth + 1});
-                        } else refs[i] = cover[i].ref;
-                    }
-                    write_node((size_t)cur.slot, cover, refs);
-                }
-            }
-            if (nodesw.empty()) nodesw.resize(STRIDE4);
-            const size_t n_nodesw = nodesw.size() / STRIDE4;
-            nodesw.resize(nodesw.size() + STRIDE4);
-            write_node(n_nodesw, std::vector<ChildW>(), std::vector<int32_t>()); // the empty node behind the tree
-            sc->dev.emptyw_off = (uint32_t)(n_nodesw * STRIDE4 * 16);
-            sc->nodesw.upload(nodesw);
-            sc->dev.nodesw = sc->nodesw.p;
-            sc->dev.rootw = rootw;
-            sc->depthw = depthw;
-            sc->n_nodesw = (uint32_t)n_nodesw;
-            if (std::getenv("CRT_SAH_TIMING")) std::fprintf(stderr, "wide tree: W %d, %zu nodes, depth %d\n", W, n_nodesw, depthw);
-        }
-#endif
         sc->dev.coord_max = coord_max;
         sc->depth4 = depth4;
         sc->accel.n_nodes4 = (uint32_t)n_nodes4; sc->accel.depth2 = (uint32_t)depth; sc->accel.depth4 = (uint32_t)depth4;
         sc->ref16_ok = n_nodes4 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
         sc->ref16_inner_ok = n_nodes4 <= 32768;
-#if CRT_WIDE != 4
-        sc->ref16_inner_ok = sc->ref16_inner_ok && sc->n_nodesw <= 32768;
-#endif
         sc->dec_ok = leaf_geo.size() / 5 <= (size_t)LEAF_REC_MAX + 1;
         sc->accel.layout_caps = (sc->ref16_ok ? 1u : 0u) | (sc->ref16_inner_ok ? 2u : 0u) | (sc->dec_ok ? 4u : 0u);
         std::vector<float4> tri_nm(d->n_tris);
@@ -1201,9 +1066,6 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->n_mats = d->n_materials;
         // Both traversal modes hold at most one pending sibling per tree level.
         sc->stack_cap = std::max(depth + 2, 3 * sc->depth4 + 2); // BVH2: one pending sibling per level; BVH4: up to three
-#if CRT_WIDE != 4
-        sc->stack_cap = std::max(sc->stack_cap, (CRT_WIDE - 1) * sc->depthw + 2);
-#endif
         *out = sc;
         return CRT_OK;
     } catch (const HipFail& f) {
