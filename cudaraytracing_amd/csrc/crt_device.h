@@ -32,6 +32,10 @@ namespace crtdev {
 #define CRT_BOUNCE_STACK_SIZE 64   /* reference: include/Global.h:18 */
 #define CRT_TILE 8                 /* pixel tile edge used for sharding */
 
+#define TNM_MAT(w_) ((w_) & 0x3fffffffu)       /* tri_nm row, word 3: the material index ... */
+#define TNM_EMITTER(w_) (((w_) >> 30) & 1u)  /* ... "its material emits" (Render.cuh:210) ... */
+#define TNM_SPECULAR(w_) ((w_) >> 31)          /* ... "its material is SPECULAR" (Render.cuh:294) */
+
 struct DevScene {
     const float4* nodes;
     const float4* tri_geo;
@@ -61,7 +65,7 @@ struct DevScene {
                              // (-DCRT_NODE_SIGNSEL=0: the round-1 layout, child pairs as in nodes3, NaN boxes for empty slots)
     int32_t root4;           // root of the 4-wide tree (a leaf ref if the scene is a single leaf)
     float coord_max;         // largest |coordinate| of a box of the 4-wide tree, +inf if one is not finite (start_ray: which rays may walk it)
-    const float4* tri_nm;    // (normal.xyz, bits(material)) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
+    const float4* tri_nm;    // (normal.xyz, bits(material | emitter << 30 | SPECULAR << 31): TNM_*) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
     uint32_t empty4_off;     // byte offset in nodes4 of a node of four empty slots, behind the tree (the decoupled-leaves step parks idle lanes there)
 };
 

@@ -204,10 +204,12 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     //   round 2: material rows of the vertex the samples belong to after this visit (the new one for ST_HIT), row 1 of the
     //   vertex the ray left (specular flag, ST_HIT), and the light of the sample that is set up below
     //   (the vn plane of a slot's very first vertex has never been written: the speculative index is clamped into the table)
-    const uint32_t mat_old = min(__float_as_uint(vn.w), P.n_mats - 1u);
-    const uint32_t mat_cur = stage == ST_HIT ? __float_as_uint(gq_hit.w) : mat_old;
-    float4 m0_cur = mat_row(tb, mat_cur, 0), m1_cur = mat_row(tb, mat_cur, 1);
-    const float4 pm1_old = mat_row(tb, mat_old, 1);
+    // (round 6: "is an emitter" / "is SPECULAR" ride in the two top bits of the triangle row's material word -- rows 1 of two materials were
+    // fetched for those two bits alone, and what bounds this kernel is the NUMBER of vector-memory instructions)
+    const uint32_t mat_old = min(TNM_MAT(__float_as_uint(vn.w)), P.n_mats - 1u);
+    const uint32_t mat_cur = stage == ST_HIT ? TNM_MAT(__float_as_uint(gq_hit.w)) : mat_old;
+    uint32_t tnm_cur = stage == ST_HIT ? __float_as_uint(gq_hit.w) : __float_as_uint(vn.w);
+    float4 m0_cur = mat_row(tb, mat_cur, 0);
     const uint32_t n_nee = (uint32_t)(sc.n_lights * P.lsn);
     const uint32_t q_next = stage == ST_SHADOW ? (st >> 16) + 1 : 0u;
     uint4 lg_next = make_uint4(0u, 1u, 0u, 0u);
@@ -215,7 +217,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     Lane s;
     s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
     s.Ld = f3(la.x, la.y, la.z);
-    s.nrm = f3(vn.x, vn.y, vn.z); s.mat = __float_as_uint(vn.w);
+    s.nrm = f3(vn.x, vn.y, vn.z); s.mat = TNM_MAT(__float_as_uint(vn.w));
     s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
     s.ro = f3(qa.x, qa.y, qa.z); s.tl = 0.0f;
     s.rd = f3(qb.x, qb.y, qb.z);
@@ -236,7 +238,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
             cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
             gst_rec(&pl.rec_a[pr].w, cos_prev);
-            if (__float_as_uint(pm1_old.w) & 2u) { // SPECULAR: emitter probe, Render.cuh:294-303
+            if (TNM_SPECULAR(__float_as_uint(vn.w))) { // SPECULAR: emitter probe, Render.cuh:294-303
                 const float ns = mat_row(tb, s.mat, 0).w;
                 const float4 pb = gld_rec(&pl.rec_b[pr]); // direction that arrived at the previous vertex
                 const float delta_coeff = (float)((double)(det_expf(25 / ns) - 1) / (2.71828182845904523536 - 1));
@@ -288,10 +290,10 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         float4 gq = gq_hit;
         if (stage == ST_PROBE) { // the vertex was found by the ray before the probe: its triangle waits in the vx plane
             gq = gld(&sc.tri_nm[s.vtri]);
-            m0_cur = mat_row(tb, __float_as_uint(gq.w), 0); m1_cur = mat_row(tb, __float_as_uint(gq.w), 1);
+            m0_cur = mat_row(tb, TNM_MAT(__float_as_uint(gq.w)), 0); tnm_cur = __float_as_uint(gq.w);
         }
         s.nrm = f3(gq.x, gq.y, gq.z);
-        s.mat = __float_as_uint(gq.w);
+        s.mat = TNM_MAT(__float_as_uint(gq.w));
         gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
         gst(&pl.vx[g], make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri)));
 #if CRT_X_NOVN
@@ -299,7 +301,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
 #else
         gst(&pl.vn[g], make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat)));
 #endif
-        if (__float_as_uint(m1_cur.w) & 1u) { // emitter: the path ends here (Render.cuh:210)
+        if (TNM_EMITTER(tnm_cur)) { // emitter: the path ends here (Render.cuh:210)
             gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16))));
             return PH3_LC;
         }
@@ -421,7 +423,7 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
         else if ((st >> 16) & 1u) {
             emissive = true;
 #if CRT_X_NOVN
-            const float4 m2 = mat_row(tb, __float_as_uint(gld(&P.sc.tri_nm[idv.w]).w), 2);
+            const float4 m2 = mat_row(tb, TNM_MAT(__float_as_uint(gld(&P.sc.tri_nm[idv.w]).w)), 2);
 #else
             const float4 m2 = mat_row(tb, __float_as_uint(gld(&pl.vn[g]).w), 2);
 #endif
@@ -437,9 +439,10 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
         } else {
             // written once, read once by k_accumulate after the launch: a streaming store keeps it from displacing the path state
             // and the scene in L2
-            __builtin_nontemporal_store(L.x, (CRT_GAS float*)&P.L[idv.z].x);
-            __builtin_nontemporal_store(L.y, (CRT_GAS float*)&P.L[idv.z].y);
-            __builtin_nontemporal_store(L.z, (CRT_GAS float*)&P.L[idv.z].z);
+            // (ONE 16-byte store -- three 4-byte ones until round 5: the instruction count is what costs)
+            typedef float f4v_ __attribute__((ext_vector_type(4)));
+            f4v_ Lv_; Lv_.x = L.x; Lv_.y = L.y; Lv_.z = L.z; Lv_.w = 0.0f;
+            __builtin_nontemporal_store(Lv_, (CRT_GAS f4v_*)&P.L[idv.z]);
         }
     }
     bool first_ = pre_ok_ && !waiting;
@@ -848,6 +851,19 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
     const float4 rf = *(const float4*)((nb + noff) + 112);
+#ifdef CRT_X_EXTRA_LOADS /* sensitivity experiment (round 6): N more loads per visit from the node's own 128-byte line (row [6]), issued with the
+                            others, consumed at the end of the visit (no wait of their own) */
+    float xl_[CRT_X_EXTRA_LOADS];
+    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) {
+        uint32_t off_ = noff;
+        asm volatile("" : "+v"(off_));
+#if defined(CRT_X_EXTRA_UNIFORM)
+        xl_[k_] = *(const float*)((nb + (off_ & 0u)) + 96); /* every lane the same address */
+#else
+        xl_[k_] = *(const float*)((nb + off_) + 96);
+#endif
+    }
+#endif
     const int top = stack_top_ahead(S, id, sp, LDS::LV);
     if (CHECK != 2) { // (the second visit of a step takes the first one's 1 / d: the same value, and a ballot of a predicate of another block is a trip through a vector register)
         const F3 inv = inv3_exact(dir);
@@ -913,6 +929,9 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     const int nref = lanes(IF) ? rF : top;
     ref = lanes(IF | POP) ? nref : ref;
     sp = sub_mask(sp_new, POP);
+#ifdef CRT_X_EXTRA_LOADS
+    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) asm volatile("" :: "v"(xl_[k_]));
+#endif
     const wmask DEEP = POP & bal(sp >= LV); // (of the new depth -- the carry instruction's own result: the compiler shares a compare of sp_new with the push block's and sends it through a vector register)
     if (DEEP) {
         if (lanes(DEEP)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
@@ -996,6 +1015,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
     uint32_t dg_ov[2] = {0, 0};                                     // STATS, per lane (DEC): visits taken back because the leaf queue was full (first visit: voided lanes; second visit: bailed, counted by its lanes)
     uint32_t lq_h = 0, lq_t = 0; // DEC: the leaf queue's head and tail, free-running (entries = tail - head, index = counter mod LEAFQ_CAP)
     constexpr bool commit_ring = RING;
+    // -DCRT_STAMPS (a diagnostic build, tools/ab_build.sh): the wave's cycles by phase -- s_memtime at the end of every step, the difference to
+    // the stamp before it booked on the step that ended (the scheduler's share on "other") -- summed into crt_stats.phase_cycles:
+    // [0] LA [1] leaf step [2] inner step [3] scheduler / rest [4] LB [5] LC, and the steps of each kind in [6..11] (same order)
+#ifdef CRT_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t st_n[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(k_) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k_] += t_ - st_prev; st_prev = t_; st_n[k_]++; }
+#define STAMP_OTHER() { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[3] += t_ - st_prev; st_prev = t_; }
+#else
+#define STAMP(k_)
+#define STAMP_OTHER()
+#endif
 #ifdef CRT_HANDOFF_INV /* experiment builds only: what a dispatch's agent-scope acquire does, by hand (vector L1 and the non-local lines of L2) */
     asm volatile("buffer_inv sc1" ::: "memory");
 #endif
@@ -1392,7 +1424,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             }
         };
-#undef PUSH_ONE
         const bool plain = MODE == 1 || n_exact == 0;
         // The two traversal steps ALTERNATE without going back to the scheduler while the other side holds a batch and no logic ring holds
         // a full one: the scheduler's comparison of the five rings (36 scalar instructions -- a third of them copies of the loop-carried
@@ -1416,10 +1447,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 bool do_inner = act == PH3_INNER;
                 for (;;) {
                     if (do_inner) {
+                        STAMP_OTHER()
                         inner_arm_dec(std::false_type{});
+                        STAMP(2)
                         if ((int)(lq_t - lq_h) < LEAFQ_FIRST || logic_waits()) break;
                     }
+                    STAMP_OTHER()
                     leaf_arm_dec();
+                    STAMP(1)
                     if (logic_waits()) break;
                     do_inner = (int)(lq_t - lq_h) < LEAFQ_FIRST;
                     if (do_inner && qn[PH3_INNER] < CHAIN_MIN) break;
@@ -1450,6 +1485,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
       }
         // (commit ring: a pool with nothing to do but slots that are held back looks at those)
         if (act == PH3_NONE && !(commit_ring && (__builtin_amdgcn_readfirstlane((int)S.waitq) & 0xff) != 0)) break;
+        STAMP_OTHER()
         if (act == PH3_LA) {
             POP3(PH3_LA)
             bool new_exact = false;
@@ -1463,6 +1499,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
+            STAMP(0)
         } else if (act == PH3_LB) {
             POP3(PH3_LB)
             bool new_exact = false;
@@ -1476,6 +1513,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
+            STAMP(4)
             // (going from here straight to LC when LC holds 16 / 32 paths -- LB's roulette stops feed it -- was measured in round 5: C2 +3.0 % / +0.7 %,
             // veach-mis +1.4 % / +1.0 %: it runs LC with emptier batches than the fullest-first rule; not kept)
         }
@@ -1535,14 +1573,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 if (held && mw == __ballot(on)) __builtin_amdgcn_s_sleep(64); // (none of them may start yet: no hurry)
                 if (lane == 0) S.waitq = (uint32_t)wn | ((uint32_t)wh << 8) | ((uint32_t)wt << 16) | (held ? 0u : 1u << 24);
             }
+            STAMP(5)
         }
     }
+#undef STAMP
+#undef STAMP_OTHER
 #undef PUSH3
+#undef PUSH_ONE
 #undef PUSH_TRAV
 #undef POP3
 #undef LOGIC_PARAMS
 
     // ---- counters ----
+#ifdef CRT_STAMPS
+    if (lane == 0) {
+        unsigned long long* cs_ = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
+        atomicAdd(&cs_[C_CYC_LOGIC], st_acc[0]); atomicAdd(&cs_[C_CYC_LEAF], st_acc[1]); atomicAdd(&cs_[C_CYC_INNER], st_acc[2]); atomicAdd(&cs_[C_CYC_OTHER], st_acc[3]);
+        atomicAdd(&cs_[C_DIAG + 0], st_acc[4]); atomicAdd(&cs_[C_DIAG + 1], st_acc[5]);
+        for (int k = 0; k < 6; k++) atomicAdd(&cs_[C_DIAG + 2 + k], (unsigned long long)st_n[k]);
+    }
+#endif
     uint32_t r = wave_sum(cnt.rays), sh = wave_sum(cnt.shadow), pr = wave_sum(cnt.probe), pa = wave_sum(cnt.paths), un = wave_sum(cnt.untraced);
     unsigned long long* cs = M.counters + (blockIdx.x & (CNT_SHARDS - 1)) * CNT_STRIDE;
     if (lane == 0 && (r | pa)) {

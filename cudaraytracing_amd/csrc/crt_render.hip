@@ -237,6 +237,7 @@ int validate_desc(const crt_scene_desc* d)
         }
         if (visited != d->n_nodes) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: nodes that the root does not reach");
     }
+    if (d->n_materials >= (1u << 30)) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: more than 2^30 - 1 materials (the triangle rows keep two flag bits beside the index)");
     for (uint32_t i = 0; i < d->n_tris; i++)
         if (d->tris[i].material < 0 || (uint32_t)d->tris[i].material >= d->n_materials) return fail(CRT_ERR_INVALID_ARG, "crt_scene_create: triangle material index out of range");
     for (uint32_t i = 0; i < d->n_light_tris; i++)
@@ -1031,7 +1032,11 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->dec_ok = leaf_geo.size() / 5 <= (size_t)LEAF_REC_MAX + 1;
         sc->accel.layout_caps = (sc->ref16_ok ? 1u : 0u) | (sc->ref16_inner_ok ? 2u : 0u) | (sc->dec_ok ? 4u : 0u);
         std::vector<float4> tri_nm(d->n_tris);
-        for (uint32_t i = 0; i < d->n_tris; i++) tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(d->tris[i].material));
+        for (uint32_t i = 0; i < d->n_tris; i++) {
+            const crt_material& m = d->materials[d->tris[i].material];
+            const int32_t w = (int32_t)((uint32_t)d->tris[i].material | (m.has_emit ? 1u << 30 : 0u) | (m.mode == 1 ? 1u << 31 : 0u)); // TNM_* (crt_device.h)
+            tri_nm[i] = make_float4(d->tris[i].normal[0], d->tris[i].normal[1], d->tris[i].normal[2], as_float(w));
+        }
         sc->nodes3.upload(nodes3); sc->leaf_geo.upload(leaf_geo); sc->tri_nm.upload(tri_nm);
         sc->dev.tri_nm = sc->tri_nm.p;
         sc->max_leaf = max_leaf;

@@ -25,5 +25,5 @@ for i in range(a.reps):
     dt = time.perf_counter() - t0
     s = r.stats
     print(json.dumps({"wall_ms": round(dt * 1e3, 1), "total_ms": round(s["total_ms"], 1), "trace_ms": round(s["kernel_ms"], 3),
-                      "logic_ms": round(s["logic_ms"], 1), "launches": s["kernel_launches"], "rays": s["rays"],
-                      "Mrays/s": round(s["rays"] / s["total_ms"] / 1e3, 1), "env": {k: v for k, v in os.environ.items() if k.startswith("CRT_")}}))
+                      "logic_ms": round(s["logic_ms"], 1), "launches": s["kernel_launches"], "rays": s["rays"], "untraced": s["rays_untraced"], "shadow": s["shadow_rays"],
+                      "Mrays/s": round(s["rays"] / s["total_ms"] / 1e3, 1), **({"stamps": s["phase_cycles"][:12]} if os.environ.get("CRT_PRINT_STAMPS") else {}), "env": {k: v for k, v in os.environ.items() if k.startswith("CRT_")}}))
