@@ -67,6 +67,14 @@ struct DevScene {
     float coord_max;         // largest |coordinate| of a box of the 4-wide tree, +inf if one is not finite (start_ray: which rays may walk it)
     const float4* tri_nm;    // (normal.xyz, bits(material | emitter << 30 | SPECULAR << 31): TNM_*) per triangle: what entering a vertex needs, 16 B instead of 48 + 4
     uint32_t empty4_off;     // byte offset in nodes4 of a node of four empty slots, behind the tree (the decoupled-leaves step parks idle lanes there)
+    // the 4-wide tree without its rows of refs (round 6, crt_render.hip "nodes4i"): 6 x float4 (96 B) per node, the same plane-major rows [0..5];
+    // nodes [0, n_mixed4i) have an inner child, the others only leaves; child refs and leaf records are implied (crt_mega3.hip: inner4_step_dec)
+    const float4* nodes4i;
+    const float4* leaf_geo_i; // leaf child k of node n: record 4 n + k (a sparse copy of leaf_geo's records, 5 x float4 each)
+    const int32_t* rec_map;   // leaf_geo record -> leaf_geo_i record (the reference-arithmetic arm walks nodes3, whose leaf refs are leaf_geo's)
+    uint32_t n_mixed4i;
+    int32_t root4i;
+    uint32_t empty4i_off;    // byte offset in nodes4i of the node of four empty slots (numbered n: a fringe node)
 };
 
 // Exact unsigned 32-bit division by a run-time constant without the ~40-instruction hardware-less

@@ -186,14 +186,14 @@ struct MParams3 {
     int32_t dbg_loads, dbg_valu; // unused by the kernel; tools/bbprof passes the address of its counter buffer in these two dwords
 };
 
-static_assert(offsetof(MParams3, dbg_loads) == 668 && offsetof(MParams3, dbg_valu) == 672, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
+static_assert(offsetof(MParams3, dbg_loads) == 748 && offsetof(MParams3, dbg_valu) == 752, "tools/bbprof/instrument.py reads the counter buffer's address from these two kernel-argument dwords");
 
 
 // ---- exported by crt_mega3.hip ----
 typedef void (*Mega3Kernel)(const MParams3);
 // The instantiation of k_mega3 for a traversal mode (0 FAST, 1 REFERENCE, 2 EXACT), with or without counters, every sample traced
 // or not, render or query form, 32- or 16-bit stack entries (never for REFERENCE), commit ring, decoupled leaves (EXACT only)
-Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring = false, bool dec = false);
+Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring = false, bool dec = false, bool impl = false); // impl: the tree without its rows of refs (dec && r16 only)
 uint32_t mega3_pool_p(bool dec, bool ring);   // rays per wave of that kernel's pool
 int mega3_lds_levels(bool dec, bool r16);     // traversal-stack levels it keeps in LDS
 bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t st); // tools/bbprof hook (false: launch as usual)

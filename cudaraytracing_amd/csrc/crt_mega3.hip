@@ -92,7 +92,7 @@ __device__ __forceinline__ F3 inv3_exact(const F3 d)
 }
 
 // Writes the new ray into the pool record `id` and returns its first phase.
-template <int MODE, bool QUERY = false, class LDS = Pool3Lds>
+template <int MODE, bool QUERY = false, class LDS = Pool3Lds, bool IMPL = false>
 __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32_t id, const NewRay& nr, PathCounters& cnt, const bool force_exact,
                                               bool& enters_exact)
 {
@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t start_ray(const DevScene& sc, LDS& S, uint32
     const bool finite = ((sc.coord_max + max_o) * max_inv <= 0x1p126f) & finite3(nr.d.x, nr.d.y, nr.d.z);
     if (MODE == 1 || !finite || force_exact) flags |= RF_EXACT;
     // (MODE 0 / 2: a ray that is not RF_EXACT walks the 4-wide tree)
-    const int ref = (MODE != 1 && finite && !force_exact) ? sc.root4 : sc.root3_exact;
+    const int ref = (MODE != 1 && finite && !force_exact) ? (IMPL ? sc.root4i : sc.root4) : sc.root3_exact; // (IMPL: the tree without its rows of refs, inner4_step_dec)
     bool answered = false;
     float T = FLT_MAX;
     if (MODE != 1 && nr.kind == RAY_SHADOW) { // REFERENCE mode resolves shadow rays with the full closest-hit query, as blocked() does
@@ -837,20 +837,23 @@ __device__ __forceinline__ int sub_mask(const int x, const wmask m)
 // EN: the lanes that take the step.  A lane outside it -- a lane without a ray, an any-hit ray that has its answer, a ray of the
 // reference-arithmetic path, a voided lane -- steps at the EMPTY node and keeps its node and depth: it hits nothing, appends nothing,
 // pushes nothing and does not pop.  Returns the lanes whose walk is over (a subset of EN); n_leaf and any_leaf accumulate.
-template <bool STATS, class LDS, int CHECK = 0>
+template <bool STATS, class LDS, int CHECK = 0, bool IMPL = false>
 __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 dir, RayPk& R,
                                                  int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, wmask& any_leaf,
                                                  int& n_leaf, const wmask EN, const uint32_t cap_left = 0, bool* bailed = nullptr, wmask* voided = nullptr)
 {
-    const char* nb = (const char*)sc.nodes4;
-    const uint32_t noff = lanes(EN) ? (uint32_t)ref * 128u : sc.empty4_off;
+    // IMPL: the copy of the tree without its rows of refs (crt_render.hip "nodes4i": 96 B per node, SIX loads per visit instead of seven -- the
+    // number of divergent vector-memory instructions is what bounds this kernel); the children's refs and the leaves' records are implied
+    const char* nb = (const char*)(IMPL ? sc.nodes4i : sc.nodes4);
+    const uint32_t noff = lanes(EN) ? (uint32_t)ref * (IMPL ? 96u : 128u) : (IMPL ? sc.empty4i_off : sc.empty4_off);
     // (the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
     const uint32_t ox = noff + ((__float_as_uint(dir.x) >> 27) & 16u), oy = noff + ((__float_as_uint(dir.y) >> 27) & 16u),
                    oz = noff + ((__float_as_uint(dir.z) >> 27) & 16u);
     const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
     const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
     const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
-    const float4 rf = *(const float4*)((nb + noff) + 112);
+    float4 rf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!IMPL) rf = *(const float4*)((nb + noff) + 112);
 #ifdef CRT_X_EXTRA_LOADS /* sensitivity experiment (round 6): N more loads per visit from the node's own 128-byte line (row [6]), issued with the
                             others, consumed at the end of the visit (no wait of their own) */
     float xl_[CRT_X_EXTRA_LOADS];
@@ -870,11 +873,29 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
         R.ixy = v2(inv.x, inv.y); R.iz.x = inv.z;
     }
     float t0, t1, t2, t3;
-    const int r0 = __float_as_int(rf.x), r1 = __float_as_int(rf.y), r2 = __float_as_int(rf.z), r3 = __float_as_int(rf.w);
+    int r0, r1, r2, r3;            // the children's refs (an inner child: its node)
+    uint32_t q0, q1, q2, q3;       // ... and what a leaf child's queue entry is made of: record << 8 (| ray)
+    wmask N0, N1, N2, N3;          // the child is a leaf (or an empty slot, which is never hit)
     wmask H0, H1, H2, H3;
     slab_quad_hits(a0, a1, a2, b0, b1, b2, R, t0, t1, t2, t3, H0, H1, H2, H3);
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-    const wmask N0 = bal(r0 < 0), N1 = bal(r1 < 0), N2 = bal(r2 < 0), N3 = bal(r3 < 0);
+    if constexpr (IMPL) {
+        // 36 bits in the low 12 mantissa bits of child 0's three NEAR planes (the same bits in the lo and the hi plane of an axis): the first
+        // mixed child fm (15), the first fringe child ff (15), the numbers of mixed and of fringe children (3 + 3).  A fringe node -- numbered
+        // from n_mixed4i on -- has leaves only and no such bits.  Inner children come first: mixed, then fringe; leaf child k is record 4 n + k.
+        const uint32_t cx = __float_as_uint(a0.x) & 0xfffu, cy = __float_as_uint(a2.x) & 0xfffu, cz = __float_as_uint(b1.x) & 0xfffu;
+        const bool fr = (uint32_t)ref >= sc.n_mixed4i;
+        const uint32_t fm = cx | ((cy & 7u) << 12), ff = (cy >> 3) | ((cz & 63u) << 9);
+        const uint32_t cm = fr ? 0u : (cz >> 6) & 7u, ci = fr ? 0u : ((cz >> 6) & 7u) + (cz >> 9);
+        N0 = bal(ci == 0u); N1 = bal(ci <= 1u); N2 = bal(ci <= 2u); N3 = bal(ci <= 3u);
+        const uint32_t ffm = ff - cm;
+        r0 = (int)(cm > 0u ? fm : ffm); r1 = (int)(cm > 1u ? fm + 1u : ffm + 1u); r2 = (int)(cm > 2u ? fm + 2u : ffm + 2u); r3 = (int)(cm > 3u ? fm + 3u : ffm + 3u);
+        q0 = (uint32_t)ref << 10; q1 = q0 + 0x100u; q2 = q0 + 0x200u; q3 = q0 + 0x300u;
+    } else {
+        r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+        N0 = bal(r0 < 0); N1 = bal(r1 < 0); N2 = bal(r2 < 0); N3 = bal(r3 < 0);
+        q0 = (uint32_t)r0 & 0x7fffff00u; q1 = (uint32_t)r1 & 0x7fffff00u; q2 = (uint32_t)r2 & 0x7fffff00u; q3 = (uint32_t)r3 & 0x7fffff00u;
+    }
     uint32_t tail = lq_t + added;
     wmask m0 = H0 & N0, m1 = H1 & N1, m2 = H2 & N2, m3 = H3 & N3;         // leaf children that are hit
     wmask i0 = H0 & ~N0, i1 = H1 & ~N1, i2 = H2 & ~N2, i3 = H3 & ~N3;     // inner children that are hit
@@ -890,10 +911,10 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     }
     const wmask EFF = CHECK == 1 ? EN & ~*voided : EN; // the lanes whose visit counts
     if (STATS && lanes(EFF)) tc.inner++;
-    leafq_push_all(S, lanes(m0), m0, ((uint32_t)r0 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, lanes(m1), m1, ((uint32_t)r1 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, lanes(m2), m2, ((uint32_t)r2 & 0x7fffff00u) | id, tail);
-    leafq_push_all(S, lanes(m3), m3, ((uint32_t)r3 & 0x7fffff00u) | id, tail);
+    leafq_push_all(S, lanes(m0), m0, q0 | id, tail);
+    leafq_push_all(S, lanes(m1), m1, q1 | id, tail);
+    leafq_push_all(S, lanes(m2), m2, q2 | id, tail);
+    leafq_push_all(S, lanes(m3), m3, q3 | id, tail);
     added = tail - lq_t;
     n_leaf = add_mask(add_mask(add_mask(add_mask(n_leaf, m0), m1), m2), m3);
     any_leaf |= (m0 | m1) | (m2 | m3);
@@ -981,9 +1002,10 @@ __device__ __forceinline__ bool inner2_step(const DevScene& sc, LDS& S, const MP
 // are not mixed with it
 // RING: the commit ring (in-order sum of the samples inside the launch, see ring_publish) -- its own instantiations: the kernels
 // without it are, instruction for instruction, what they were before it existed
-template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false, bool RING = false, bool DEC = false>
+template <int MODE, bool STATS, bool ALL = false, bool QUERY = false, bool R16 = false, bool RING = false, bool DEC = false, bool IMPL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, CRT_WAVES))) void k_mega3(const MParams3 M3)
 {
+    static_assert(!IMPL || (DEC && R16), "the tree without its rows of refs: decoupled leaves, 16-bit stack entries");
     static_assert(!(RING && (QUERY || STATS)), "the commit ring is a render without counters");
     static_assert(!(R16 && MODE == 1), "CRT_TRAVERSAL_REFERENCE walks the 2-wide trees: 32-bit stack entries");
     static_assert(!DEC || MODE == 2, "decoupled leaves: CRT_TRAVERSAL_EXACT");
@@ -1295,7 +1317,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const uint32_t lq_used = (lq_t - lq_h) + (MAY_EXACT ? 64u : 0u);
                     const uint32_t lq_free = lq_used < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used : 0u;
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
-                    DONE |= inner4_step_dec<STATS, LDS3, 1>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, GO & ~EX, lq_free, nullptr, &VOID);
+                    DONE |= inner4_step_dec<STATS, LDS3, 1, IMPL>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, GO & ~EX, lq_free, nullptr, &VOID);
                     if (STATS && lanes(GO & ~EX & VOID)) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
@@ -1312,7 +1334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                             const uint32_t lq_used2 = (lq_t + added) - lq_h;
                             const uint32_t cap_left = lq_used2 < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used2 : 0u;
                             bool bailed = false;
-                            DONE |= inner4_step_dec<STATS, LDS3, 2>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN2, cap_left, &bailed);
+                            DONE |= inner4_step_dec<STATS, LDS3, 2, IMPL>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN2, cap_left, &bailed);
                             if (STATS && bailed && lanes(EN2)) dg_ov[1]++;
                         }
                     }
@@ -1321,7 +1343,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const wmask GX = GO & EX;
                     if (GX) { // reference arithmetic on the reference topology, one thing per visit: a leaf ref becomes a queue entry, an inner node is stepped
                         const wmask LF = GX & bal(ref < 0);
-                        leafq_push(S, id, lanes(LF), LF, ((uint32_t)~ref << 8) | id, lq_t, added);
+                        uint32_t lrec = (uint32_t)~ref; // (a leaf ref of nodes3: a record of leaf_geo)
+                        if (IMPL) lrec = (uint32_t)sc.rec_map[lanes(LF) ? lrec : 0u]; // ... whose copy in leaf_geo_i the leaf step reads
+                        leafq_push(S, id, lanes(LF), LF, (lrec << 8) | id, lq_t, added);
                         bool dn = false;
                         if (lanes(GX)) {
                             if (lanes(LF)) dn = stack_pop(S, M3, id, g, sp, ref, lds_levels<LDS3>(true));
@@ -1385,7 +1409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 // (a leaf step without this loop for scenes whose leaves are one record each -- bvh_thresh_n <= 2 -- was measured in round 5: eleven
                 // instructions fewer per step, C2 +0.3 %, veach-mis +0.2 %: the second copy of the pair test costs what they save; not kept)
                 for (int k = 0; left > 0; k++, rec++) { // one record per pair of triangles: a single pass with bvh_thresh_n <= 2
-                    const float4* lg = (const float4*)((const char*)sc.leaf_geo + rec * 80u);
+                    const float4* lg = (const float4*)((const char*)(IMPL ? sc.leaf_geo_i : sc.leaf_geo) + rec * 80u);
                     const float4 g0 = lg[0], g1 = lg[1], g2 = lg[2], g3 = lg[3], g4 = lg[4];
                     const int it = __float_as_int(g4.z);
                     if (k == 0) left = __float_as_int(g4.w);
@@ -1495,7 +1519,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float4 ra_, rb_;
                 ray_result(S, id, ra_, rb_);
                 nph = logic_A<MODE, RING>(Pl, tl, g, ra_, rb_, nr, cnt, ALL);
-                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3, IMPL>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
@@ -1509,7 +1533,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float4 ra_, rb_;
                 ray_result(S, id, ra_, rb_);
                 nph = logic_B<MODE, RING>(Pl, g, ra_, rb_, nr);
-                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3, IMPL>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
             PUSH3()
@@ -1553,7 +1577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float4 ra_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb_ = ra_;
                 if (QUERY) ray_result(S, id, ra_, rb_);
                 const int got = QUERY ? (query_C(Pl, g, ra_, rb_, nr) ? LC_RAY : LC_DEAD) : logic_C<RING>(Pl, tl, g, cnt, nr, fin_key);
-                if (got == LC_RAY) nph = start_ray<MODE, QUERY, LDS3>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
+                if (got == LC_RAY) nph = start_ray<MODE, QUERY, LDS3, IMPL>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
                 wait = got == LC_WAIT;
             }
             n_exact += (int)__popcll(__ballot(new_exact));
@@ -1702,20 +1726,21 @@ void launch_order_items(bool ring, uint32_t blocks, hipStream_t st, const LParam
 }
 #ifdef CRT_ASM_ONLY_DEFAULT /* tools/diet/asm_default.sh: the default instantiation alone (a quick assembly listing; never a library) */
 #ifndef CRT_ASM_ONLY_ARGS
-#define CRT_ASM_ONLY_ARGS 2, false, false, false, true, false, true
+#define CRT_ASM_ONLY_ARGS 2, false, false, false, true, false, true, true
 #endif
-Mega3Kernel mega3_kernel(int, bool, bool, bool, bool, bool, bool) { return (Mega3Kernel)k_mega3<CRT_ASM_ONLY_ARGS>; }
+Mega3Kernel mega3_kernel(int, bool, bool, bool, bool, bool, bool, bool) { return (Mega3Kernel)k_mega3<CRT_ASM_ONLY_ARGS>; }
 #else
-template <bool R16, bool DEC> Mega3Kernel mega3_exact_kernel(bool stats, bool all, bool query, bool ring)
+template <bool R16, bool DEC, bool IMPL = false> Mega3Kernel mega3_exact_kernel(bool stats, bool all, bool query, bool ring)
 {
-    if (ring) return all ? (Mega3Kernel)k_mega3<2, false, true, false, R16, true, DEC> : (Mega3Kernel)k_mega3<2, false, false, false, R16, true, DEC>;
-    if (query) return (Mega3Kernel)k_mega3<2, false, false, true, R16, false, DEC>;
-    if (all) return stats ? (Mega3Kernel)k_mega3<2, true, true, false, R16, false, DEC> : (Mega3Kernel)k_mega3<2, false, true, false, R16, false, DEC>;
-    return stats ? (Mega3Kernel)k_mega3<2, true, false, false, R16, false, DEC> : (Mega3Kernel)k_mega3<2, false, false, false, R16, false, DEC>;
+    if (ring) return all ? (Mega3Kernel)k_mega3<2, false, true, false, R16, true, DEC, IMPL> : (Mega3Kernel)k_mega3<2, false, false, false, R16, true, DEC, IMPL>;
+    if (query) return (Mega3Kernel)k_mega3<2, false, false, true, R16, false, DEC, IMPL>;
+    if (all) return stats ? (Mega3Kernel)k_mega3<2, true, true, false, R16, false, DEC, IMPL> : (Mega3Kernel)k_mega3<2, false, true, false, R16, false, DEC, IMPL>;
+    return stats ? (Mega3Kernel)k_mega3<2, true, false, false, R16, false, DEC, IMPL> : (Mega3Kernel)k_mega3<2, false, false, false, R16, false, DEC, IMPL>;
 }
-Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring, bool dec)
+Mega3Kernel mega3_kernel(int mode, bool stats, bool all, bool query, bool r16, bool ring, bool dec, bool impl)
 {
     if (mode == 2) {
+        if (dec && r16 && impl) return mega3_exact_kernel<true, true, true>(stats, all, query, ring);
         if (dec) return r16 ? mega3_exact_kernel<true, true>(stats, all, query, ring) : mega3_exact_kernel<false, true>(stats, all, query, ring);
         return r16 ? mega3_exact_kernel<true, false>(stats, all, query, ring) : mega3_exact_kernel<false, false>(stats, all, query, ring);
     }
@@ -1749,9 +1774,10 @@ bool bbprof_launch(Mega3Kernel kern, MParams3 M3, uint32_t blocks, hipStream_t s
 #ifdef CRT_ASM_ONLY_DEFAULT
     const char* sym = nullptr;
 #else
-    const char* sym = kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, true>    ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1EEEvNS_8MParams3E"
-                      : kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, false> ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0EEEvNS_8MParams3E"
-                                                                                                  : nullptr;
+    const char* sym = kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, true, true>    ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1ELb1EEEvNS_8MParams3E"
+                      : kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, true, false>  ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1ELb0EEEvNS_8MParams3E"
+                      : kern == (Mega3Kernel)k_mega3<2, false, false, false, true, false, false, false> ? "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb0ELb0EEEvNS_8MParams3E"
+                                                                                                         : nullptr;
 #endif
     if (!co || !*co || !sym) return false;
     enum { N_CNT = 4096, STRIDE = 128 };

@@ -12,6 +12,7 @@
 #include <limits>
 #include <string>
 #include <type_traits>
+#include <array>
 #include <vector>
 
 using namespace crtdev;
@@ -19,7 +20,9 @@ using namespace crtk;
 
 struct crt_scene {
     int device = 0;
-    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4;
+    DevBuf<float4> nodes, tri_geo, mats, ltri, nodes3, leaf_geo, tri_nm, nodes4, nodes4i, leaf_geo_i;
+    DevBuf<int32_t> rec_map;
+    bool impl_ok = false;        // the implicit-refs copy of the 4-wide tree exists (nodes4i: leaves of one record, <= 32 768 nodes)
     int depth4 = 1; // depth of the 4-wide tree
     bool ref16_ok = false; // refs of the 4-wide tree and of the leaf records fit 16 bits (k_mega3's 16-bit stack layout)
     bool ref16_inner_ok = false; // refs of the 4-wide tree alone fit 16 bits (decoupled leaves: the stack holds inner nodes only)
@@ -288,6 +291,14 @@ static bool use_dec(const crt_scene* sc, int mode)
     if (e && e[0] == '1') return true;
     return sc->ref16_inner_ok;
 }
+// The copy of the 4-wide tree without its rows of refs (nodes4i, round 6): the decoupled-leaves kernels with 16-bit stack entries take it
+// whenever the scene offers it (crt_scene::impl_ok: leaves of one record, <= 32 768 nodes); CRT_IMPL=0 keeps them on nodes4 (tests, A/B).
+static bool use_impl(const crt_scene* sc, bool dec, bool r16)
+{
+    if (!dec || !r16 || !sc->impl_ok) return false;
+    const char* e = std::getenv("CRT_IMPL");
+    return !(e && e[0] == '0');
+}
 // Which pipeline renders: 4 = k_mega3 (the product), 2 = the wavefront pipeline (k_logic + k_trace).  k_mega3 keeps the best
 // triangle's offset inside its leaf in 16 bits, addresses nodes and leaf records with 32-bit byte offsets and the traversal stack
 // depth in 8 bits; scenes beyond any of these fall back to the wavefront pipeline, which has no such limits.  The CRT_TEST_*
@@ -422,7 +433,8 @@ int render_impl(crt_scene* sc, const crt_camera* cam, const crt_params* prm, voi
             const int mode3 = reference ? 1 : exact ? 2 : 0;
             const bool dec = use_dec(sc, mode3);
             const bool r16 = use_ref16(sc, mode3, dec);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16, ring.samples != 0, dec);
+            const bool impl = use_impl(sc, dec, r16);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, want_stats, mode3 != 1 && (prm->flags & CRT_FLAG_TRACE_ALL) != 0, false, r16, ring.samples != 0, dec, impl);
             const uint32_t pool_p = mega3_pool_p(dec, ring.samples != 0);
             MParams M;
             std::memset(&M, 0, sizeof(M));
@@ -867,6 +879,8 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         }
         // ---- 4-wide tree for the rays with finite operands: the SAH tree collapsed (crt_device.h, nodes4) ----
         std::vector<float4> nodes4;
+        struct Topo4 { bool used[4]; int32_t ref[4]; float lo[4][3], hi[4][3]; }; // the 4-wide tree as built below, by node: what the implicit-refs copy is made from
+        std::vector<Topo4> topo;
         float coord_max = 0.0f; // largest |coordinate| of a box of the 4-wide tree (+inf if any is not finite): start_ray's overflow test
         int32_t root4 = ref3(root_fast);
         int depth4 = 1;
@@ -980,6 +994,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                 }
                 int32_t refs[4];
                 float lo[4][3], hi[4][3];
+                if (topo.size() <= (size_t)cur.slot) topo.resize((size_t)cur.slot + 1);
                 for (int i = 0; i < 4; i++) {
                     if (i < (int)ch.size()) {
                         for (int a = 0; a < 3; a++) { lo[i][a] = ch[i].lo[a]; hi[i][a] = ch[i].hi[a]; }
@@ -993,6 +1008,10 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                         for (int a = 0; a < 3; a++) { lo[i][a] = std::numeric_limits<float>::infinity(); hi[i][a] = -std::numeric_limits<float>::infinity(); }
                         refs[i] = ~0x7ffffff0; // (never followed)
                     }
+                    Topo4& tp = topo[(size_t)cur.slot];
+                    tp.used[i] = i < (int)ch.size();
+                    tp.ref[i] = refs[i];
+                    for (int a = 0; a < 3; a++) { tp.lo[i][a] = lo[i][a]; tp.hi[i][a] = hi[i][a]; }
                 }
                 for (int i = 0; i < (int)ch.size() && i < 4; i++)
                     for (int a = 0; a < 3; a++) {
@@ -1021,6 +1040,129 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             nodes4.push_back(make_float4(er, er, er, er)); nodes4.push_back(make_float4(er, er, er, er));
             sc->dev.empty4_off = (uint32_t)(n_nodes4 * 128);
         }
+        // ---- the same tree WITHOUT its rows of refs (round 6): nodes4i, 6 x float4 (96 B) per node ----
+        // What bounds k_mega3 is the number of divergent vector-memory instructions (one more 4-byte load per inner visit costs
+        // the stand-in 2.1 % and veach-mis 6.7 %; 9 % fewer vector ALU instructions cost nothing), and a visit loads seven float4 -- six rows
+        // of planes and the refs.  Here the refs are IMPLIED:
+        //   * nodes are numbered breadth first in two ranges: [0, n_mixed) the nodes with an inner child, [n_mixed, n) the nodes whose
+        //     children are all leaves ("fringe"); a node's children are ordered mixed, fringe, leaves, empty, so that its mixed children
+        //     are fm, fm + 1, .. and its fringe children ff, ff + 1, ..;
+        //   * leaf child k of node n is record 4 n + k of a SPARSE copy of the leaf records (leaf_geo_i; leaves of one record only:
+        //     bvh_thresh_n <= 2, else the layout is not offered);
+        //   * (fm, ff, number of mixed, number of fringe children) -- 36 bits -- live in the low 12 mantissa bits of the six planes of
+        //     child 0 of a mixed node, which is an INNER child: the same 12 bits in the lo and in the hi plane of an axis (a ray reads them
+        //     from the near plane whatever its direction), the planes moved OUTWARDS to the next value with those bits (a box grows by at
+        //     most 2^-11 of its coordinates).  An inner box may be any superset (crt_trace.h); a leaf's box stays the reference's own, bit
+        //     for bit -- which is why the bits can only live in an inner child, and why the fringe nodes are told apart by their number.
+        // Offered when it applies (crt_scene::impl_ok); the decoupled-leaves kernels with 16-bit stack entries take it (CRT_IMPL=0: not).
+        sc->impl_ok = false;
+        if (root4 >= 0 && n_nodes4 <= 32768 && max_leaf <= 2 && topo.size() == n_nodes4) {
+            const size_t n4 = n_nodes4;
+            std::vector<uint8_t> mixed(n4, 0);
+            for (size_t i = 0; i < n4; i++)
+                for (int k = 0; k < 4; k++) if (topo[i].used[k] && topo[i].ref[k] >= 0) mixed[i] = 1;
+            // children order: mixed, fringe, leaves, empty; then breadth-first numbers in the two ranges
+            std::vector<std::array<int, 4>> order(n4);
+            for (size_t i = 0; i < n4; i++) {
+                int o = 0;
+                for (int pass = 0; pass < 4; pass++)
+                    for (int k = 0; k < 4; k++) {
+                        const Topo4& t = topo[i];
+                        const int cls = !t.used[k] ? 3 : (t.ref[k] < 0 ? 2 : (mixed[(size_t)t.ref[k]] ? 0 : 1));
+                        if (cls == pass) order[i][o++] = k;
+                    }
+            }
+            uint32_t n_mixed = 0;
+            for (size_t i = 0; i < n4; i++) n_mixed += mixed[i];
+            std::vector<int32_t> newid(n4, -1);
+            {
+                uint32_t cm_ = 0, cf_ = n_mixed;
+                std::vector<int32_t> bfs;
+                bfs.push_back(0);
+                newid[0] = mixed[0] ? (int32_t)cm_++ : (int32_t)cf_++;
+                for (size_t t = 0; t < bfs.size(); t++) {
+                    const int32_t i = bfs[t];
+                    for (int o = 0; o < 4; o++) {
+                        const int k = order[(size_t)i][o];
+                        if (!topo[(size_t)i].used[k] || topo[(size_t)i].ref[k] < 0) continue;
+                        const int32_t c = topo[(size_t)i].ref[k];
+                        newid[(size_t)c] = mixed[(size_t)c] ? (int32_t)cm_++ : (int32_t)cf_++;
+                        bfs.push_back(c);
+                    }
+                }
+            }
+            auto raw = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+            auto unraw = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+            bool ok = true;
+            // the nearest value <= f (down) / >= f (up) whose low 12 bits are `chunk`
+            auto with_bits = [&](float f, uint32_t chunk, bool up) -> float {
+                if (!(std::fabs(f) <= FLT_MAX)) { ok = false; return f; }
+                const uint32_t r = raw(f);
+                const bool neg = (r >> 31) != 0;
+                uint32_t m = r & 0x7fffffffu; // magnitude: grows with |f|
+                const bool grow = neg ? !up : up; // does the magnitude have to grow?
+                uint32_t c = (m & ~0xfffu) | chunk;
+                if (grow) { if (c < m) c += 0x1000u; }
+                else if (c > m) {
+                    if (c >= 0x1000u) c -= 0x1000u;
+                    else { // |f| below the smallest magnitude with these bits: cross zero -- the smallest magnitude of the other sign
+                        const uint32_t other = chunk | (neg ? 0u : 0x80000000u);
+                        return unraw(other);
+                    }
+                }
+                if (c >= 0x7f800000u) { ok = false; return f; }
+                return unraw(c | (neg ? 0x80000000u : 0u));
+            };
+            std::vector<float4> n4i((n4 + 1) * 6);
+            const size_t n_rec_i = (n4 + 1) * 4;
+            std::vector<float4> lgi(n_rec_i * 5, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            std::vector<int32_t> rec_map(leaf_geo.size() / 5, 0);
+            float cmax_i = coord_max;
+            for (size_t i = 0; i < n4 && ok; i++) {
+                const Topo4& t = topo[i];
+                const size_t ni = (size_t)newid[i];
+                float lo[4][3], hi[4][3];
+                uint32_t n_m = 0, n_f = 0, fm = 0, ff = 0;
+                for (int o = 0; o < 4; o++) {
+                    const int k = order[i][o];
+                    for (int a = 0; a < 3; a++) { lo[o][a] = t.lo[k][a]; hi[o][a] = t.hi[k][a]; }
+                    if (t.used[k] && t.ref[k] >= 0) {
+                        const uint32_t id = (uint32_t)newid[(size_t)t.ref[k]];
+                        if (mixed[(size_t)t.ref[k]]) { if (n_m++ == 0) fm = id; } else { if (n_f++ == 0) ff = id; }
+                    } else if (t.used[k]) { // a leaf of one record: its copy at 4 n + o
+                        const size_t dense = (size_t)(~t.ref[k]);
+                        const size_t sparse = ni * 4 + (size_t)o;
+                        for (int q = 0; q < 5; q++) lgi[sparse * 5 + (size_t)q] = leaf_geo[dense * 5 + (size_t)q];
+                        rec_map[dense] = (int32_t)sparse;
+                    }
+                }
+                if (mixed[i]) {
+                    const uint32_t chunk[3] = {fm & 0xfffu, ((fm >> 12) & 7u) | ((ff & 0x1ffu) << 3), ((ff >> 9) & 63u) | (n_m << 6) | (n_f << 9)};
+                    for (int a = 0; a < 3; a++) {
+                        lo[0][a] = with_bits(lo[0][a], chunk[a], false);
+                        hi[0][a] = with_bits(hi[0][a], chunk[a], true);
+                        const float m = std::max(std::fabs(lo[0][a]), std::fabs(hi[0][a]));
+                        cmax_i = std::max(cmax_i, m);
+                    }
+                }
+                float4* o6 = &n4i[ni * 6];
+                for (int a = 0; a < 3; a++) {
+                    o6[2 * a + 0] = make_float4(lo[0][a], lo[1][a], lo[2][a], lo[3][a]);
+                    o6[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]);
+                }
+            }
+            if (ok && cmax_i <= FLT_MAX) {
+                const float pinf_ = std::numeric_limits<float>::infinity();
+                for (int a = 0; a < 3; a++) { n4i[n4 * 6 + 2 * (size_t)a] = make_float4(pinf_, pinf_, pinf_, pinf_); n4i[n4 * 6 + 2 * (size_t)a + 1] = make_float4(-pinf_, -pinf_, -pinf_, -pinf_); }
+                sc->nodes4i.upload(n4i); sc->leaf_geo_i.upload(lgi); sc->rec_map.upload(rec_map);
+                sc->dev.nodes4i = sc->nodes4i.p; sc->dev.leaf_geo_i = sc->leaf_geo_i.p; sc->dev.rec_map = sc->rec_map.p;
+                sc->dev.n_mixed4i = n_mixed;
+                sc->dev.root4i = newid[0];
+                sc->dev.empty4i_off = (uint32_t)(n4 * 96);
+                coord_max = cmax_i; // (start_ray's overflow test covers both copies of the tree)
+                sc->impl_ok = true;
+            }
+        }
         sc->nodes4.upload(nodes4);
         sc->dev.nodes4 = sc->nodes4.p;
         sc->dev.root4 = root4;
@@ -1030,7 +1172,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
         sc->ref16_ok = n_nodes4 <= 32768 && leaf_geo.size() / 5 <= 32768; // node refs 0 .. 32767, leaf refs ~0 .. ~32767
         sc->ref16_inner_ok = n_nodes4 <= 32768;
         sc->dec_ok = leaf_geo.size() / 5 <= (size_t)LEAF_REC_MAX + 1;
-        sc->accel.layout_caps = (sc->ref16_ok ? 1u : 0u) | (sc->ref16_inner_ok ? 2u : 0u) | (sc->dec_ok ? 4u : 0u);
+        sc->accel.layout_caps = (sc->ref16_ok ? 1u : 0u) | (sc->ref16_inner_ok ? 2u : 0u) | (sc->dec_ok ? 4u : 0u) | (sc->impl_ok ? 8u : 0u);
         std::vector<float4> tri_nm(d->n_tris);
         for (uint32_t i = 0; i < d->n_tris; i++) {
             const crt_material& m = d->materials[d->tris[i].material];
@@ -1268,7 +1410,7 @@ int crt_intersect(crt_scene* sc, uint32_t n, const float* origins, const float* 
             const int mode3 = reference ? 1 : exact ? 2 : 0;
             const bool dec = use_dec(sc, mode3);
             const bool r16 = use_ref16(sc, mode3, dec);
-            const Mega3Kernel kern3 = mega3_kernel(mode3, false, false, true, r16, false, dec);
+            const Mega3Kernel kern3 = mega3_kernel(mode3, false, false, true, r16, false, dec, use_impl(sc, dec, r16));
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern3, 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
             const uint32_t pool_p = mega3_pool_p(dec, false);
             const uint32_t blocks = std::min<uint32_t>((n + pool_p - 1) / pool_p, (uint32_t)(sc->n_cus * per_cu));

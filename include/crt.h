@@ -197,7 +197,8 @@ typedef struct {
     uint32_t layout_caps;     /* which pool layouts of the render kernel the scene allows: bit 0 = node AND leaf refs fit 16-bit stack
                                  entries (coupled form, 8 LDS levels), bit 1 = the four-wide nodes alone do (decoupled leaves, 6 levels:
                                  what a scene of roughly 50 000 - 160 000 triangles renders with), bit 2 = leaf records fit a leaf-queue
-                                 entry (decoupled leaves possible at all) */
+                                 entry (decoupled leaves possible at all), bit 3 = the copy of the four-wide tree without its rows of refs
+                                 exists (at most 32 768 nodes, leaves of one record -- bvh_thresh_n <= 2: six loads per inner visit instead of seven) */
 } crt_accel_info;
 int crt_scene_accel_info(crt_scene* scene, crt_accel_info* out);
 /* replaces Render::free (Render.cuh:477-487) */

@@ -452,10 +452,11 @@ def test_raw_directions_with_infinite_components():
         r.free()
 
 
-LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_render.hip: use_dec, use_ref16)
+LAYOUTS = {  # environment of each form of k_mega3's pool (csrc/crt_render.hip: use_dec, use_ref16, use_impl)
     "coupled-16": {"CRT_DEC": "0"},
     "coupled-32": {"CRT_DEC": "0", "CRT_REF16": "0"},
-    "decoupled-16": {"CRT_DEC": "1"},
+    "decoupled-16": {"CRT_DEC": "1"},                       # (on the tree without its rows of refs where the scene offers it: both shipped scenes do)
+    "decoupled-16, rows of refs": {"CRT_DEC": "1", "CRT_IMPL": "0"},
     "decoupled-32": {"CRT_DEC": "1", "CRT_REF32": "1"},
     "default": {},  # decoupled-16 for CRT_TRAVERSAL_EXACT on a scene of up to about 160 000 triangles, coupled-16 for the other modes
     "default, leaf records beyond 16 bits": {"CRT_REF16": "0"},  # a scene of 50 000 - 160 000 triangles: coupled-32 for the other modes
@@ -478,7 +479,7 @@ def test_all_stack_layouts(name, monkeypatch):
         o, d = util.random_rays(name, 4096, seed=17)
         otri, ot, _ = osc.intersect(o, d)
         for layout, env in LAYOUTS.items():
-            for k in ("CRT_DEC", "CRT_REF16", "CRT_REF32"):
+            for k in ("CRT_DEC", "CRT_REF16", "CRT_REF32", "CRT_IMPL"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)

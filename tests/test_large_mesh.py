@@ -50,7 +50,7 @@ def test_a_102412_triangle_mesh_on_the_large_mesh_layout(big, monkeypatch):
     try:
         ai = r.accel_info()
         assert ai["n_leaves"] > 32768 and ai["n_nodes4"] <= 32768
-        assert ai["layout_caps"] == 2 | 4     # leaf refs beyond 16 bits, four-wide nodes within: decoupled leaves, 16-bit stack entries
+        assert ai["layout_caps"] == 2 | 4 | 8  # leaf refs beyond 16 bits, four-wide nodes within: decoupled leaves, 16-bit stack entries, on the tree without rows of refs
         # ---- crops of the 800 x 600 frame against the oracle ----
         r.traversal = crt.TRAVERSAL_EXACT
         rgb = r.run_view(eye, iv, fov, width=800, height=600)

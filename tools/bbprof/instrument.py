@@ -33,7 +33,7 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     opts = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
     src, sym, dst, meta = args[:4]
-    karg_off = int(opts.get("kernarg-off", "668"), 0)
+    karg_off = int(opts.get("kernarg-off", "748"), 0)
     lines = open(src).read().split("\n")
 
     # ---- cut the translation unit down to: header directives, the kernel's section, its descriptor and metadata ----

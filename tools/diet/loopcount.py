@@ -4,7 +4,7 @@ compiler's assembly: tools/bbprof/asm.sh out.s ; tools/diet/loopcount.py out.s [
 instructions by kind (vector / scalar / branch / wait / LDS / memory) and the source lines they come from, and the totals -- a quick
 local reading of what an edit did to the steps before an A/B on the GPU (the dynamic truth is tools/bbprof)."""
 import re, sys, collections
-SYM = "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1EEEvNS_8MParams3E"
+SYM = "_ZN4crtk7k_mega3ILi2ELb0ELb0ELb0ELb1ELb0ELb1ELb1EEEvNS_8MParams3E"
 
 def kind(op):
     if op.startswith("v_"): return "valu"
