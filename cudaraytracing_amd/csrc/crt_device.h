@@ -32,6 +32,9 @@ namespace crtdev {
 #define CRT_BOUNCE_STACK_SIZE 64   /* reference: include/Global.h:18 */
 #define CRT_TILE 8                 /* pixel tile edge used for sharding */
 
+#ifndef NODE4I_F4
+#define NODE4I_F4 6 /* float4 per node of nodes4i: six rows of planes (96 B); 8 = padded to one 128-byte line per node (an A/B of round 6) */
+#endif
 #define TNM_MAT(w_) ((w_) & 0x3fffffffu)       /* tri_nm row, word 3: the material index ... */
 #define TNM_EMITTER(w_) (((w_) >> 30) & 1u)  /* ... "its material emits" (Render.cuh:210) ... */
 #define TNM_SPECULAR(w_) ((w_) >> 31)          /* ... "its material is SPECULAR" (Render.cuh:294) */

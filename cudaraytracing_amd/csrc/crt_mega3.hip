@@ -845,7 +845,7 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     // IMPL: the copy of the tree without its rows of refs (crt_render.hip "nodes4i": 96 B per node, SIX loads per visit instead of seven -- the
     // number of divergent vector-memory instructions is what bounds this kernel); the children's refs and the leaves' records are implied
     const char* nb = (const char*)(IMPL ? sc.nodes4i : sc.nodes4);
-    const uint32_t noff = lanes(EN) ? (uint32_t)ref * (IMPL ? 96u : 128u) : (IMPL ? sc.empty4i_off : sc.empty4_off);
+    const uint32_t noff = lanes(EN) ? (uint32_t)ref * (IMPL ? (uint32_t)(NODE4I_F4 * 16) : 128u) : (IMPL ? sc.empty4i_off : sc.empty4_off);
     // (the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
     const uint32_t ox = noff + ((__float_as_uint(dir.x) >> 27) & 16u), oy = noff + ((__float_as_uint(dir.y) >> 27) & 16u),
                    oz = noff + ((__float_as_uint(dir.z) >> 27) & 16u);

@@ -288,8 +288,9 @@ static bool use_dec(const crt_scene* sc, int mode)
     if (mode != 2 || !sc->dec_ok) return false;
     const char* e = std::getenv("CRT_DEC");
     if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
-    return sc->ref16_inner_ok;
+    // (round 6: also beyond 32 768 four-wide nodes, where its stack has three 32-bit levels in LDS -- a 348 172-triangle cornell-box
+    // --detail 7,5, 88 230 nodes: 14.6 ms at spp 64 against 16.1 ms of the coupled form with 32-bit entries, tools/big_mesh_probe.py)
+    return true;
 }
 // The copy of the 4-wide tree without its rows of refs (nodes4i, round 6): the decoupled-leaves kernels with 16-bit stack entries take it
 // whenever the scene offers it (crt_scene::impl_ok: leaves of one record, <= 32 768 nodes); CRT_IMPL=0 keeps them on nodes4 (tests, A/B).
@@ -1113,7 +1114,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                 if (c >= 0x7f800000u) { ok = false; return f; }
                 return unraw(c | (neg ? 0x80000000u : 0u));
             };
-            std::vector<float4> n4i((n4 + 1) * 6);
+            std::vector<float4> n4i((n4 + 1) * (size_t)NODE4I_F4, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             const size_t n_rec_i = (n4 + 1) * 4;
             std::vector<float4> lgi(n_rec_i * 5, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             std::vector<int32_t> rec_map(leaf_geo.size() / 5, 0);
@@ -1145,7 +1146,7 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
                         cmax_i = std::max(cmax_i, m);
                     }
                 }
-                float4* o6 = &n4i[ni * 6];
+                float4* o6 = &n4i[ni * (size_t)NODE4I_F4];
                 for (int a = 0; a < 3; a++) {
                     o6[2 * a + 0] = make_float4(lo[0][a], lo[1][a], lo[2][a], lo[3][a]);
                     o6[2 * a + 1] = make_float4(hi[0][a], hi[1][a], hi[2][a], hi[3][a]);
@@ -1153,12 +1154,12 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             }
             if (ok && cmax_i <= FLT_MAX) {
                 const float pinf_ = std::numeric_limits<float>::infinity();
-                for (int a = 0; a < 3; a++) { n4i[n4 * 6 + 2 * (size_t)a] = make_float4(pinf_, pinf_, pinf_, pinf_); n4i[n4 * 6 + 2 * (size_t)a + 1] = make_float4(-pinf_, -pinf_, -pinf_, -pinf_); }
+                for (int a = 0; a < 3; a++) { n4i[n4 * (size_t)NODE4I_F4 + 2 * (size_t)a] = make_float4(pinf_, pinf_, pinf_, pinf_); n4i[n4 * (size_t)NODE4I_F4 + 2 * (size_t)a + 1] = make_float4(-pinf_, -pinf_, -pinf_, -pinf_); }
                 sc->nodes4i.upload(n4i); sc->leaf_geo_i.upload(lgi); sc->rec_map.upload(rec_map);
                 sc->dev.nodes4i = sc->nodes4i.p; sc->dev.leaf_geo_i = sc->leaf_geo_i.p; sc->dev.rec_map = sc->rec_map.p;
                 sc->dev.n_mixed4i = n_mixed;
                 sc->dev.root4i = newid[0];
-                sc->dev.empty4i_off = (uint32_t)(n4 * 96);
+                sc->dev.empty4i_off = (uint32_t)(n4 * NODE4I_F4 * 16);
                 coord_max = cmax_i; // (start_ray's overflow test covers both copies of the tree)
                 sc->impl_ok = true;
             }

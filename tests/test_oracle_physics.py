@@ -201,3 +201,78 @@ def test_one_bounce_is_the_expectation_of_the_reference_estimator(tmp_path):
             assert (indirect > 0.02).all()                            # the bounce is what this pixel is made of
             err = np.abs(mean[py, px] - want)
             assert (err <= 4.0 * se[py, px] + 3e-3 * want).all(), (px, py, mean[py, px], want, se[py, px], direct)
+
+
+def test_specular_probe_is_the_expectation_of_the_reference_estimator(tmp_path):
+    """3. The SPECULAR emitter probe (Render.cuh:294-314): the one term of the integrator that had no check outside the
+    author's own reading.  A plate with Ns = 100 (Loader.h:107: Ns > 1 is SPECULAR) under a rectangular emitter and a huge BLACK ceiling
+    (kd = 0: whatever comes back from it is multiplied by f_r = 0, so the indirect term of the plate is exactly zero -- but a bounce that
+    meets it makes the plate a vertex that is not the path's last, which is when the probe is evaluated, :289, :294).  For a pixel on
+    the plate
+        E = E_direct(x0) + P_RR * p(x0) * E_eta[ hit(eta) * (0.5 log10(ns) + 1) * ke (.) kd * max(dir_y, 0) * 2 pi / 8 ] ,
+    p = the share of the uniform hemisphere (Global.h:57-66) in which the bounce meets the emitter or the ceiling, eta = (eta1, eta2) uniform
+    on (-1, 1]^2, dir(eta) the lobe sample of Global.h:68-94 around the mirror direction of the camera ray -- polar angle from +z, azimuth
+    in the xy plane, half-widths (exp(25 / ns) - 1) / (e - 1) * (30, 120) degrees --, hit = "the probe's first surface is the emitter".
+    The emitter cuts the lobe's footprint, so the lobe's frame, its widths, the shininess factor, the cosine and the 2 pi / 8 all show."""
+    ns = 100.0
+    mtl = "newmtl plate\nKd 0.6 0.5 0.4\nNs 100\nnewmtl black\nKd 0 0 0\nNs 1\nnewmtl light\nKe 20 15 10\nKd 0 0 0\nNs 1\n"
+    kd_plate = np.array([0.6, 0.5, 0.4])
+    plate = [(-2, 0, -2), (-2, 0, 2), (2, 0, 2), (2, 0, -2)]                       # normal +y
+    hl, hc = 3.0, 10.0
+    lx0, lx1, lz0, lz1 = -0.6, 1.5, 5.2, 7.0
+    light = [(lx0, hl, lz0), (lx1, hl, lz0), (lx1, hl, lz1), (lx0, hl, lz1)]       # normal -y
+    big = 600.0
+    ceiling = [(-big, hc, -big), (big, hc, -big), (big, hc, big), (-big, hc, big)]  # normal -y
+    obj, mdir = _write(str(tmp_path), "probe", [("plate", plate), ("black", ceiling), ("light", light)], mtl)
+    osc = O.OracleScene([(obj, mdir)], 2)
+    lt = _tris_of(light)
+    assert osc.num_lights == 1 and (_normal(lt[0]) == -UP).all() and (_normal(_tris_of(plate)[0]) == UP).all()
+    eye = np.array([0.8, 2.0, -4.0], dtype=np.float32)
+    iv = O.inverse_view(eye, [0.3, 0.0, 0.2], [0.0, 1.0, 0.0])
+    fov, W, H, lsn, p_rr = np.float32(np.deg2rad(8.0)), 2, 2, 1, 0.5
+    mean, se = _oracle_pixels(osc, eye, iv, fov, W, H, 16384, p_rr, lsn, seeds=(1, 2, 3, 4))
+    delta = (np.exp(25.0 / ns) - 1.0) / (np.e - 1.0)
+    d_theta, d_phi = delta * 30.0 * PI / 180.0, delta * 120.0 * PI / 180.0
+    shininess = 0.5 * np.log10(ns) + 1.0
+    nj, ne, nh = 4, 500, 600
+    j = (np.arange(nj) + 0.5) / nj
+    ja, jb = np.meshgrid(j, j, indexing="ij")
+    e = -1.0 + 2.0 * (np.arange(ne) + 0.5) / ne
+    e1, e2 = np.meshgrid(e, e, indexing="ij")
+    hs = (np.arange(nh) + 0.5) / nh
+    s1, s2 = np.meshgrid(hs, hs, indexing="ij")
+    z = np.abs(1.0 - 2.0 * s1)
+    rr = np.sqrt(1.0 - z * z)
+    w = np.stack([rr * np.cos(2 * PI * s2), z, rr * np.sin(2 * PI * s2)], axis=-1)   # uniform hemisphere around +y (to_world of N = +y)
+
+    def meets(q, d, h, x0, x1, z0, z1):
+        s = (h - q[1]) / np.where(d[..., 1] > 1e-12, d[..., 1], np.inf)
+        px, pz = q[0] + s * d[..., 0], q[2] + s * d[..., 2]
+        return (d[..., 1] > 1e-12) & (px > x0) & (px < x1) & (pz > z0) & (pz < z1)
+
+    eye64 = eye.astype(np.float64)
+    for py in range(H):
+        for px in range(W):
+            x0 = _camera_points(eye64, iv, float(fov), W, H, px, py, ja, jb)          # (nj, nj, 3) on the plate
+            assert (np.abs(x0[..., 0]) < 2).all() and (np.abs(x0[..., 2]) < 2).all()
+            direct = _direct(x0, UP, lt, KE, kd_plate, nu=96).mean(axis=(0, 1))
+            probe = np.zeros(3)
+            cut = []
+            for q in x0.reshape(-1, 3):
+                # the bounce leaves the plate as a vertex that is not the last one iff it meets the emitter or the ceiling
+                p_nf = (meets(q, w, hl, lx0, lx1, lz0, lz1) | meets(q, w, hc, -big, big, -big, big)).mean()
+                din = (q - eye64) / np.linalg.norm(q - eye64)                          # from_dir of vertex 0
+                out = din - 2.0 * din.dot(UP) * UP
+                th0 = np.arccos(out[2] / np.linalg.norm(out))
+                ph0 = (PI / 2 if out[1] > 0 else -PI / 2) if abs(out[0]) < 1e-5 else np.arctan2(out[1], out[0])
+                th, ph = th0 + e1 * d_theta, ph0 + e2 * d_phi
+                d = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=-1)
+                hit = meets(q, d, hl, lx0, lx1, lz0, lz1)                              # (nothing else lies below the emitter's plane)
+                g = (hit * np.clip(d[..., 1], 0.0, None)).mean()
+                cut.append(hit.mean())
+                probe += p_rr * p_nf * g * shininess * KE * kd_plate * (2.0 * PI / 8.0)
+            probe /= nj * nj
+            want = direct + probe
+            assert (probe > 5.0 * direct).all() and 0.1 < float(np.mean(cut)) < 0.9   # the probe is what the pixel is made of, and the emitter cuts the lobe
+            err = np.abs(mean[py, px] - want)
+            assert (err <= 4.0 * se[py, px] + 3e-3 * want).all(), (px, py, mean[py, px], want, se[py, px], direct, probe)
