@@ -35,7 +35,10 @@ bound; `roofline.bound` is the unit that is busiest BY THE HARDWARE'S OWN COUNTE
                hardware's own counter).  Beside them: `frac_at_mix_cost` (the count priced with the cycles per instruction of THIS
                kernel's opcode mix: the exact census of tools/bbprof x the per-opcode costs of tools/valu_issue_gen.py) and
                `arith_share` (share of the vector instructions that are box / triangle arithmetic);
-    l2         TCC requests x 128 B / t against the L2 peak.
+    l2         TCC requests x 128 B / t against the L2 peak;
+    vmem_ta    the vector-memory pipe: TA_TA_BUSY (texture addressers busy) / all cycles as `frac`; beside it the rate of wave64 vector-memory
+               instructions against one per 16 cycles per CU.  roofline.sensitivity (profiles/r06_experiments/sensitivity.json) holds the
+               A/B pairs that say which of these the frame time actually follows.
 The SURVEY 8(d) contract figure -- algorithmic bytes of the REFERENCE traversal's visit set, B_ray = 64 x inner
 visits + 8 x leaf visits + 36 x triangle tests + 16 x hits, counted by the exhaustive kernel on a spp=8 slice --
 stays as `contract_*` side fields: the production traversal walks a 4-wide SAH tree over the reference's leaves and
@@ -248,6 +251,19 @@ def bounds_from_pmc(pmc, k_s, census=None):
                            "pmc_over_census_instructions": round(pmc["SQ_INSTS_VALU"] / census["valu_instructions_per_launch"], 4),
                            "source": "tools/bbprof (exact dynamic opcode counts of the production ISA) x tools/valu_issue_gen.py (measured per-opcode issue costs)"}
         out["valu_issue"] = v
+    if pmc.get("ta_busy_frac") is not None:
+        # The vector-memory pipe: cycles in which a CU's texture addresser (the unit every global load / store of its 16 waves passes) was busy
+        # / all cycles -- the hardware's own counter, like valu_busy_hw.  Round 6's A/B pairs (profiles/r06_experiments/sensitivity.json) say
+        # this is the unit the frame time follows: 9 % fewer vector ALU instructions moved nothing, one more divergent load per inner visit
+        # costs 2 - 7 %.  `achieved` / `peak` in wave64 vector-memory instructions per second against one per 16 cycles per CU (64 lanes, 4 per clock).
+        ach = (pmc.get("SQ_INSTS_VMEM") or 0.0) / k_s / 1e9
+        peak = 256 * CLOCK_GHZ / 16.0
+        t = {"achieved": round(ach, 2), "peak": round(peak, 2), "unit": "G wave-instr/s (vector memory)", "peak_note": "256 CUs x clock / 16 cycles per wave64 instruction (4 lanes per clock through the addresser)",
+             "l1_tag_lookups_per_instr": pmc.get("l1_tag_lookups_per_vmem_instr"), "l2_read_requests_per_instr": pmc.get("l2_read_requests_per_vmem_instr"),
+             "l1_miss_latency_cycles": pmc.get("l1_read_latency_cycles")}
+        put_frac(t, ach / peak, "frac_at_16_cycles")
+        put_frac(t, float(pmc["ta_busy_frac"]))
+        out["vmem_ta"] = t
     if pmc.get("TCC_REQ_sum") is not None or (pmc.get("TCC_HIT_sum") is not None and pmc.get("TCC_MISS_sum") is not None):
         req = pmc.get("TCC_REQ_sum")
         if req is None:
@@ -261,7 +277,8 @@ def bounds_from_pmc(pmc, k_s, census=None):
 def pick_bound(bounds):
     """The unit that is busiest by the hardware's own account names the bound: for the vector pipes that is `valu_busy_hw` (cycles in
     which a SIMD's vector unit executed / all SIMD cycles -- a counter, not a priced instruction mix), for the memory side and L2 their
-    bytes against the datasheet peak.  A candidate whose raw fraction exceeds 1 is suspect and cannot win."""
+    bytes against the datasheet peak, for the vector-memory pipe `vmem_ta` the texture addressers' busy cycles / all cycles (a counter too).
+    A candidate whose raw fraction exceeds 1 is suspect and cannot win."""
     best, best_f = None, -1.0
     for name, b in bounds.items():
         if b.get("suspect"):
@@ -544,12 +561,23 @@ def main_rank(args):
                     # the vector pipes' busy cycles against all SIMD cycles (the hardware's counter): achieved / peak in SIMD-cycles per second
                     roofline.update({"bound": name, "achieved": round(f * N_SIMDS * CLOCK_GHZ, 1), "peak": round(N_SIMDS * CLOCK_GHZ, 1),
                                      "unit": "G SIMD-cycles/s busy (SQ_ACTIVE_INST_VALU x 4)", "frac": f})
+                elif name == "vmem_ta":
+                    # the texture addressers' busy cycles against all their cycles (256 of them, one per CU): achieved / peak in TA-cycles per second
+                    roofline.update({"bound": name, "achieved": round(f * 256 * CLOCK_GHZ, 1), "peak": round(256 * CLOCK_GHZ, 1),
+                                     "unit": "G TA-cycles/s busy (TA_TA_BUSY: the vector-memory pipe)", "frac": f})
                 elif name is not None:
                     roofline.update({"bound": name, "achieved": bounds[name]["achieved"], "peak": bounds[name]["peak"],
                                      "unit": bounds[name]["unit"], "frac": bounds[name]["frac"]})
             if "memory_side" in bounds:
                 roofline["traffic"] = bounds["memory_side"]["bytes_per_launch"]
                 roofline["traffic_note"] = "L2 <-> fabric bytes (Infinity-Cache hits included; no DRAM-only counter is exposed): bounds.memory_side"
+            try:
+                ev = json.load(open(os.path.join(ROOT, "profiles", "r06_experiments", "sensitivity.json")))
+                roofline["sensitivity"] = {"source": "profiles/r06_experiments/sensitivity.json (A/B pairs of round 6, each on one box)", "reading": ev["reading"],
+                                           "rows": [{"change": r_["change"], "effect": r_["effect"]} for r_ in ev["rows"]],
+                                           "phase_share_of_wave_cycles": {k_: v_ for k_, v_ in ev["phase_share_of_wave_cycles"].items() if k_ != "veach_mis_spp256"}}
+            except Exception:
+                pass
             roofline["pmc"] = {"src_hash": B.source_hash(), "collected": pmc.get("collected"), "profiled_launch_ms": pmc.get("avg_launch_ms"),
                                "salu_per_valu": pmc.get("salu_per_valu"), "wait_any_frac": pmc.get("SQ_WAIT_ANY/WAVE_CYCLES"),
                                "tcc_miss_frac": pmc.get("tcc_miss_frac")}

@@ -34,6 +34,9 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 namespace crtaccel {
 
@@ -341,7 +344,17 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
     const int A = (int)nodes.size();
     if (A < 3 || passes <= 0) return optimize_sah_serial(nodes, passes);
     if (n_threads <= 0) {
-        n_threads = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+        // The CPUs this process may RUN on (its affinity mask: a cgroup's cpuset or taskset shows here; hardware_concurrency() counts the
+        // machine's) decide: the speculative form pays only from four threads on (measured: 32 ms serial, 43 / 36 / 28 / 21 ms on 1 / 2 / 4 / 8
+        // threads, profiles/r05_experiments/sah_opt_threads.txt), and its helpers spin -- with fewer CPUs, or when eight ranks of one node
+        // build their trees at once on a share of the cores each, the serial form is the faster one.
+        unsigned usable = std::max(1u, std::thread::hardware_concurrency());
+#if defined(__linux__)
+        cpu_set_t set_;
+        CPU_ZERO(&set_);
+        if (sched_getaffinity(0, sizeof(set_), &set_) == 0) usable = (unsigned)std::max(1, CPU_COUNT(&set_));
+#endif
+        n_threads = usable >= 4 ? (int)std::min(8u, usable) : 1;
         if (const char* e_ = std::getenv("CRT_SAH_OPT_THREADS")) n_threads = std::max(1, std::atoi(e_));
         if (n_threads == 1) return optimize_sah_serial(nodes, passes); // (one thread: the serial form does without the read sets and the overlay)
     }
@@ -458,6 +471,9 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
         std::atomic<int> gen{0}, running{0};
         std::atomic<bool> quit{false};
         const std::function<void(int)>* job = nullptr;
+        // (whatever ends this function -- a bad_alloc of one of the vectors below included -- the helpers are told to leave and joined: a
+        // joinable std::thread that is destroyed calls std::terminate)
+        ~Pool() { quit.store(true, std::memory_order_release); for (std::thread& x : th) if (x.joinable()) x.join(); }
     } pool;
     for (int k = 1; k < n_threads; k++)
         pool.th.emplace_back([&pool, k] {
@@ -547,6 +563,7 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
     }
     pool.quit.store(true, std::memory_order_release);
     for (std::thread& th : pool.th) th.join();
+    pool.th.clear();
     // back to the breadth-first array of inner nodes
     std::vector<int> order, index((size_t)n_all, -1), dep;
     order.push_back(root); dep.push_back(1); index[root] = 0;

@@ -226,7 +226,14 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
     }
     if (gather == CRT_GATHER_RCCL && !distinct) return mfail(CRT_ERR_INVALID_ARG, "crt_multi_create: RCCL needs one rank per device (duplicate device index)");
     const uint32_t requested = gather;
-    if (gather == CRT_GATHER_AUTO) gather = (distinct && n_devices > 1) ? CRT_GATHER_RCCL : CRT_GATHER_COPY;
+    // Test hooks (the fallback below could not run on a one-GPU box).  CRT_TEST_RCCL_AUTO_ONE_DEVICE=1: AUTO attempts RCCL with a
+    // single device too (a one-rank communicator).  CRT_TEST_RCCL_FAIL=load | init | count: the binding of librccl is treated as failed /
+    // the communicator is made, then treated as failed and destroyed / ncclCommCount is treated as reporting another number of ranks.
+    const char* t_one_ = std::getenv("CRT_TEST_RCCL_AUTO_ONE_DEVICE");
+    const char* t_fail_ = std::getenv("CRT_TEST_RCCL_FAIL");
+    const std::string inject = t_fail_ ? t_fail_ : "";
+    const bool auto_one = t_one_ && t_one_[0] == '1';
+    if (gather == CRT_GATHER_AUTO) gather = (distinct && (n_devices > 1 || auto_one)) ? CRT_GATHER_RCCL : CRT_GATHER_COPY;
     DeviceGuard guard;
     crt_multi* m = nullptr;
     try {
@@ -250,6 +257,7 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
             std::string why;
             Rccl& R = rccl();
             if (!R.ok) why = R.error;
+            else if (inject == "load") why = "cannot load librccl.so.1: (injected by CRT_TEST_RCCL_FAIL=load)";
             else {
                 std::vector<ncclComm_t> comms(n_devices, nullptr);
                 std::vector<int> devs(devices, devices + n_devices);
@@ -259,8 +267,9 @@ int crt_multi_create(const crt_scene_desc* desc, const int* devices, uint32_t n_
                     for (uint32_t r = 0; r < n_devices; r++) m->ranks[r].comm = comms[r];
                     rv = R.CommCount(comms[0], &m->rccl_ranks);
                 }
-                if (rv != ncclSuccess) {
-                    why = std::string("ncclCommInitAll / ncclCommCount: ") + R.GetErrorString(rv);
+                if (rv == ncclSuccess && inject == "count") m->rccl_ranks = (int)n_devices + 1;
+                if (rv != ncclSuccess || inject == "init") {
+                    why = std::string("ncclCommInitAll / ncclCommCount: ") + (rv != ncclSuccess ? R.GetErrorString(rv) : "(injected by CRT_TEST_RCCL_FAIL=init)");
                     for (uint32_t r = 0; r < n_devices; r++) {
                         if (m->ranks[r].comm) { (void)hipSetDevice(m->ranks[r].device); (void)R.CommDestroy(m->ranks[r].comm); m->ranks[r].comm = nullptr; }
                     }

@@ -167,18 +167,52 @@ def test_bench_c4_resolution_on_four_self_started_ranks(single, tmp_path):
 
 def test_auto_gather_records_why_it_fell_back(single, monkeypatch):
     """CRT_GATHER_AUTO never fails a frame because of RCCL: distinct devices whose communicator cannot be made render by peer copies and
-    crt_multi_info.fallback_reason says why (ABI 5).  On this one-GPU box AUTO with one device is a one-rank RCCL communicator (no fallback:
-    the reason is empty and ncclCommCount is 1), and with a repeated device it is peer copies by rule (no attempt, no reason)."""
+    crt_multi_info.fallback_reason says why (ABI 5).  AUTO takes RCCL only with two or more distinct devices, which this one-GPU box cannot
+    offer: with one device, or a repeated one, it is peer copies by rule (no attempt, no reason).  The fallback itself runs here through the
+    library's test hooks (crt_multi.hip): CRT_TEST_RCCL_AUTO_ONE_DEVICE=1 makes AUTO attempt a one-rank communicator, CRT_TEST_RCCL_FAIL
+    fails its binding / its creation (after the real communicator was made: the clean-up runs) / its rank count.  Every fallback renders the
+    one-device frame; an explicit CRT_GATHER_RCCL with the same failure fails loudly and leaves the library usable."""
     eye, iv, fov = util.camera("cornell-box")
-    for devices, want_gather, want_ranks in (([0], None, None), ([0, 0], crt.GATHER_COPY, 0)):
+    one = single["cornell-box"]
+    one.set_spp(2)
+    one.traversal = crt.TRAVERSAL_EXACT
+    want_rgb = one.run_view(eye, iv, fov, width=64, height=40).copy()
+    for k in ("CRT_TEST_RCCL_AUTO_ONE_DEVICE", "CRT_TEST_RCCL_FAIL"):
+        monkeypatch.delenv(k, raising=False)
+    for devices in ([0], [0, 0]):
         m = _multi("cornell-box", devices, crt.GATHER_AUTO, 2)
         try:
-            m.run_view(eye, iv, fov, width=64, height=40)
-            assert m.info["fallback_reason"] == ""
-            if want_gather is not None:
-                assert m.info["gather"] == want_gather and m.info["rccl_ranks"] == want_ranks
+            rgb = m.run_view(eye, iv, fov, width=64, height=40)
+            assert m.info["fallback_reason"] == "" and m.info["gather"] == crt.GATHER_COPY and m.info["rccl_ranks"] == 0
+            assert np.array_equal(rgb, want_rgb)
         finally:
             m.free()
+    monkeypatch.setenv("CRT_TEST_RCCL_AUTO_ONE_DEVICE", "1")
+    m = _multi("cornell-box", [0], crt.GATHER_AUTO, 2)          # no failure: a one-rank RCCL communicator
+    try:
+        rgb = m.run_view(eye, iv, fov, width=64, height=40)
+        assert m.info["fallback_reason"] == "" and m.info["gather"] == crt.GATHER_RCCL and m.info["rccl_ranks"] == 1
+        assert np.array_equal(rgb, want_rgb)
+    finally:
+        m.free()
+    for how, text in (("load", "cannot load librccl"), ("init", "ncclCommInitAll"), ("count", "ncclCommCount reports 2 ranks for 1 devices")):
+        monkeypatch.setenv("CRT_TEST_RCCL_FAIL", how)
+        m = _multi("cornell-box", [0], crt.GATHER_AUTO, 2)
+        try:
+            rgb = m.run_view(eye, iv, fov, width=64, height=40)
+            assert text in m.info["fallback_reason"], (how, m.info["fallback_reason"])
+            assert m.info["gather"] == crt.GATHER_COPY and m.info["rccl_ranks"] == 0
+            assert np.array_equal(rgb, want_rgb), how
+        finally:
+            m.free()
+        with pytest.raises(Exception):                            # asked for by name, RCCL's failure is the caller's
+            _multi("cornell-box", [0], crt.GATHER_RCCL, 2)
+    monkeypatch.delenv("CRT_TEST_RCCL_FAIL")
+    m = _multi("cornell-box", [0], crt.GATHER_RCCL, 2)           # ... and the library is as usable as before
+    try:
+        assert np.array_equal(m.run_view(eye, iv, fov, width=64, height=40), want_rgb) and m.info["rccl_ranks"] == 1
+    finally:
+        m.free()
 
 
 def test_bench_multi_engine_one_process(single):

@@ -26,7 +26,12 @@ groups=(
 "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_32B_sum"
 "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum"
 "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum"
+"TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max"
+"TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_TCP_LATENCY_sum"
+"TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum TCP_TAGRAM2_REQ_sum TCP_TAGRAM3_REQ_sum"
 )
+# (round 6: the vector-memory pipe -- texture addresser busy cycles, the L1's requests to L2 and their latency, its tag lookups.  Groups of
+# TA / TCP stall counters made rocprofv3 abort on this pool (tools/pmc_mem.sh, four of eight passes): only the three that ran are collected)
 # (round 5: the L2's fabric-side request counters by size -- FETCH_SIZE / WRITE_SIZE are derived from them with one assumed size; the
 # _32B forms count 32-byte units whatever the request's size, i.e. exact bytes.  "DRAM" = destined for the device's own memory, which
 # includes what the Infinity Cache in front of it answers: this rocprofv3 exposes no counter behind that cache, rocprofv3 --list-avail)

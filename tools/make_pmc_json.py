@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 from cudaraytracing_amd import build as B
 
 # the default render path: EXACT traversal (FAST as a fallback for older profiles), no counting, zero-contribution samples answered without traversal, not the query form
-DEFAULT_KERNEL = ("k_mega3<2, false, false, false, true, false, true>", "k_mega3<2, false, false, false, true, false, false>",   # (MODE, STATS, ALL, QUERY, R16, RING, DEC)
+DEFAULT_KERNEL = ("k_mega3<2, false, false, false, true, false, true, true>", "k_mega3<2, false, false, false, true, false, true, false>",   # (MODE, STATS, ALL, QUERY, R16, RING, DEC, IMPL)
+                  "k_mega3<2, false, false, false, true, false, true>", "k_mega3<2, false, false, false, true, false, false>",   # (MODE, STATS, ALL, QUERY, R16, RING, DEC)
                   "k_mega3<2, false, false, false, false, false, true>", "k_mega3<2, false, false, false, false, false, false>",
                   "k_mega3<2, false, false, false, true, false>", "k_mega3<2, false, false, false, false, false>",   # (MODE, STATS, ALL, QUERY, R16, RING)
                   "k_mega3<2, false, false, false, true>", "k_mega3<2, false, false, false, false>",
@@ -69,6 +70,15 @@ for wl, desc in (("c2", "cornell-box 800x600 spp=512"), ("c3", "veach-mis 800x60
         w["fabric_write_bytes"] = 32.0 * (v["TCC_EA0_WRREQ_WRITE_DRAM_32B_sum"] + v.get("TCC_EA0_WRREQ_ATOMIC_DRAM_32B_sum", 0.0))
         if v.get("TCC_EA0_RDREQ_sum"):
             w["fabric_read_bytes_per_request"] = round(w["fabric_read_bytes"] / v["TCC_EA0_RDREQ_sum"], 2)
+    if v.get("TA_TA_BUSY_sum") is not None and v.get("GRBM_GUI_ACTIVE"):
+        # texture addressers (one per CU, 256) busy / all their cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        w["ta_busy_frac"] = round(v["TA_TA_BUSY_sum"] / (32.0 * v["GRBM_GUI_ACTIVE"]), 4)
+    if v.get("TCP_TCC_READ_REQ_sum"):
+        w["l1_read_latency_cycles"] = round(v.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / v["TCP_TCC_READ_REQ_sum"], 1)
+        if v.get("SQ_INSTS_VMEM"):
+            w["l2_read_requests_per_vmem_instr"] = round(v["TCP_TCC_READ_REQ_sum"] / v["SQ_INSTS_VMEM"], 3)
+    if all(v.get("TCP_TAGRAM%d_REQ_sum" % i) is not None for i in range(4)) and v.get("SQ_INSTS_VMEM"):
+        w["l1_tag_lookups_per_vmem_instr"] = round(sum(v["TCP_TAGRAM%d_REQ_sum" % i] for i in range(4)) / v["SQ_INSTS_VMEM"], 3)
     if v.get("SQ_LDS_BANK_CONFLICT") is not None and v.get("SQ_LDS_IDX_ACTIVE"):
         w["lds_conflict_frac"] = round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 4)
     res["workloads"][wl] = w
