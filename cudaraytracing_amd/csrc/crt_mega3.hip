@@ -831,72 +831,81 @@ __device__ __forceinline__ int sub_mask(const int x, const wmask m)
     return r;
 }
 
-// CHECK: what happens when the queue cannot take the visit's entries (they are counted before anything is written).  0: cannot happen (the
-// caller cut the batch to a quarter of the free entries); 1: the lanes from `cap_left / 4` on are taken out of the visit (*voided: they keep
-// their state and are queued again); 2: the whole visit is dropped (*bailed).
-// EN: the lanes that take the step.  A lane outside it -- a lane without a ray, an any-hit ray that has its answer, a ray of the
-// reference-arithmetic path, a voided lane -- steps at the EMPTY node and keeps its node and depth: it hits nothing, appends nothing,
-// pushes nothing and does not pop.  Returns the lanes whose walk is over (a subset of EN); n_leaf and any_leaf accumulate.
-template <bool STATS, class LDS, int CHECK = 0, bool IMPL = false>
-__device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const F3 dir, RayPk& R,
-                                                 int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, wmask& any_leaf,
-                                                 int& n_leaf, const wmask EN, const uint32_t cap_left = 0, bool* bailed = nullptr, wmask* voided = nullptr)
+// A visit of the decoupled inner step, in three parts so that the caller can put the SECOND visit's loads in front of the first visit's
+// stores (round 6: what a wave waits for in this step is the node's round trip, ~500 cycles; the first visit's appends and pushes -- some
+// eighty instructions that touch LDS only -- now run while the second visit's node is on its way):
+//   node_load    the six (seven) rows of the node
+//   visit_front  boxes, accept masks, the queue-capacity check, entry counts, the nearest inner child, the new node and depth -- registers only
+//   visit_back   the leaf-queue entries, the stack pushes (LDS; spilled levels: global memory)
+struct Visit4 {
+    float4 a0, a1, a2, b0, b1, b2, rf;     // near / far rows of x, y, z; the row of refs (not IMPL)
+    wmask m0, m1, m2, m3;                  // leaf children that are hit
+    wmask pd, pg, pb;                      // inner children that are hit and pushed: the loser of (2,3), of the final, of (0,1)
+    uint32_t q0, q1, q2, q3, tail;         // queue entries (record << 8) and where the visit's first one goes
+    int rd, rg, rb, l3, l2, l1, sp_new;    // the pushed refs, their levels, the depth after the pushes
+};
+template <bool IMPL>
+__device__ __forceinline__ void node_load(const DevScene& sc, const int ref, const wmask EN, const F3 dir, Visit4& V)
 {
-    // IMPL: the copy of the tree without its rows of refs (crt_render.hip "nodes4i": 96 B per node, SIX loads per visit instead of seven -- the
-    // number of divergent vector-memory instructions is what bounds this kernel); the children's refs and the leaves' records are implied
+    // IMPL: the copy of the tree without its rows of refs (crt_render.hip "nodes4i": 96 B per node, SIX loads per visit instead of seven);
+    // the children's refs and the leaves' records are implied.  A lane outside EN loads the EMPTY node.
     const char* nb = (const char*)(IMPL ? sc.nodes4i : sc.nodes4);
     const uint32_t noff = lanes(EN) ? (uint32_t)ref * (IMPL ? (uint32_t)(NODE4I_F4 * 16) : 128u) : (IMPL ? sc.empty4i_off : sc.empty4_off);
-    // (the argument is the direction itself -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
+    // (the direction itself picks the planes -- 1 / d has d's sign -- and the reciprocals are formed after the loads are on their way)
     const uint32_t ox = noff + ((__float_as_uint(dir.x) >> 27) & 16u), oy = noff + ((__float_as_uint(dir.y) >> 27) & 16u),
                    oz = noff + ((__float_as_uint(dir.z) >> 27) & 16u);
-    const float4 a0 = *(const float4*)(nb + ox), a1 = *(const float4*)(nb + (ox ^ 16u));
-    const float4 a2 = *(const float4*)((nb + oy) + 32), b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
-    const float4 b1 = *(const float4*)((nb + oz) + 64), b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
-    float4 rf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (!IMPL) rf = *(const float4*)((nb + noff) + 112);
-#ifdef CRT_X_EXTRA_LOADS /* sensitivity experiment (round 6): N more loads per visit from the node's own 128-byte line (row [6]), issued with the
-                            others, consumed at the end of the visit (no wait of their own) */
-    float xl_[CRT_X_EXTRA_LOADS];
-    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) {
-        uint32_t off_ = noff;
-        asm volatile("" : "+v"(off_));
-#if defined(CRT_X_EXTRA_UNIFORM)
-        xl_[k_] = *(const float*)((nb + (off_ & 0u)) + 96); /* every lane the same address */
-#else
-        xl_[k_] = *(const float*)((nb + off_) + 96);
-#endif
-    }
-#endif
-    const int top = stack_top_ahead(S, id, sp, LDS::LV);
+    V.a0 = *(const float4*)(nb + ox); V.a1 = *(const float4*)(nb + (ox ^ 16u));
+    V.a2 = *(const float4*)((nb + oy) + 32); V.b0 = *(const float4*)((nb + (oy ^ 16u)) + 32);
+    V.b1 = *(const float4*)((nb + oz) + 64); V.b2 = *(const float4*)((nb + (oz ^ 16u)) + 64);
+    V.rf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!IMPL) V.rf = *(const float4*)((nb + noff) + 112);
+}
+// CHECK: what happens when the queue cannot take the visit's entries (they are counted before anything is written).  0: cannot happen;
+// 1: the lanes from `cap_left / 4` on are taken out of the visit (*voided: they keep their state and are queued again); 2: the whole
+// visit is dropped (*bailed; nothing has changed).
+// EN: the lanes that take the visit.  A lane outside it -- a lane without a ray, an any-hit ray that has its answer, a ray of the
+// reference-arithmetic path, a voided lane -- is at the EMPTY node and keeps its node and depth: it hits nothing, appends nothing,
+// pushes nothing and does not pop.  Returns the lanes whose walk is over (a subset of EN); n_leaf and any_leaf accumulate.
+// `top`: the stack's top level as it is when the visit begins (read after the visit before it has pushed).
+template <bool STATS, class LDS, int CHECK = 0, bool IMPL = false>
+__device__ __forceinline__ wmask visit_front(const DevScene& sc, const MParams3& M, const uint32_t g, const F3 dir, RayPk& R, Visit4& V, const int top,
+                                             int& ref, int& sp, TravCounters& tc, uint32_t& max_sp, const uint32_t lq_t, uint32_t& added, wmask& any_leaf,
+                                             int& n_leaf, const wmask EN, const uint32_t cap_left = 0, bool* bailed = nullptr, wmask* voided = nullptr)
+{
     if (CHECK != 2) { // (the second visit of a step takes the first one's 1 / d: the same value, and a ballot of a predicate of another block is a trip through a vector register)
         const F3 inv = inv3_exact(dir);
         R.ixy = v2(inv.x, inv.y); R.iz.x = inv.z;
     }
+#ifdef CRT_X_EXTRA_VALU /* sensitivity experiment (round 6): N more vector instructions per visit (independent v_add_f32 on a scratch register) */
+    {
+        float xv_ = dir.x;
+        for (int k_ = 0; k_ < CRT_X_EXTRA_VALU; k_++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(xv_) : "v"(dir.y));
+        asm volatile("" :: "v"(xv_));
+    }
+#endif
     float t0, t1, t2, t3;
     int r0, r1, r2, r3;            // the children's refs (an inner child: its node)
-    uint32_t q0, q1, q2, q3;       // ... and what a leaf child's queue entry is made of: record << 8 (| ray)
     wmask N0, N1, N2, N3;          // the child is a leaf (or an empty slot, which is never hit)
     wmask H0, H1, H2, H3;
-    slab_quad_hits(a0, a1, a2, b0, b1, b2, R, t0, t1, t2, t3, H0, H1, H2, H3);
+    slab_quad_hits(V.a0, V.a1, V.a2, V.b0, V.b1, V.b2, R, t0, t1, t2, t3, H0, H1, H2, H3);
     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
     if constexpr (IMPL) {
         // 36 bits in the low 12 mantissa bits of child 0's three NEAR planes (the same bits in the lo and the hi plane of an axis): the first
         // mixed child fm (15), the first fringe child ff (15), the numbers of mixed and of fringe children (3 + 3).  A fringe node -- numbered
         // from n_mixed4i on -- has leaves only and no such bits.  Inner children come first: mixed, then fringe; leaf child k is record 4 n + k.
-        const uint32_t cx = __float_as_uint(a0.x) & 0xfffu, cy = __float_as_uint(a2.x) & 0xfffu, cz = __float_as_uint(b1.x) & 0xfffu;
+        const uint32_t cx = __float_as_uint(V.a0.x) & 0xfffu, cy = __float_as_uint(V.a2.x) & 0xfffu, cz = __float_as_uint(V.b1.x) & 0xfffu;
         const bool fr = (uint32_t)ref >= sc.n_mixed4i;
         const uint32_t fm = cx | ((cy & 7u) << 12), ff = (cy >> 3) | ((cz & 63u) << 9);
         const uint32_t cm = fr ? 0u : (cz >> 6) & 7u, ci = fr ? 0u : ((cz >> 6) & 7u) + (cz >> 9);
         N0 = bal(ci == 0u); N1 = bal(ci <= 1u); N2 = bal(ci <= 2u); N3 = bal(ci <= 3u);
         const uint32_t ffm = ff - cm;
         r0 = (int)(cm > 0u ? fm : ffm); r1 = (int)(cm > 1u ? fm + 1u : ffm + 1u); r2 = (int)(cm > 2u ? fm + 2u : ffm + 2u); r3 = (int)(cm > 3u ? fm + 3u : ffm + 3u);
-        q0 = (uint32_t)ref << 10; q1 = q0 + 0x100u; q2 = q0 + 0x200u; q3 = q0 + 0x300u;
+        V.q0 = (uint32_t)ref << 10; V.q1 = V.q0 + 0x100u; V.q2 = V.q0 + 0x200u; V.q3 = V.q0 + 0x300u;
     } else {
-        r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
+        r0 = __float_as_int(V.rf.x); r1 = __float_as_int(V.rf.y); r2 = __float_as_int(V.rf.z); r3 = __float_as_int(V.rf.w);
         N0 = bal(r0 < 0); N1 = bal(r1 < 0); N2 = bal(r2 < 0); N3 = bal(r3 < 0);
-        q0 = (uint32_t)r0 & 0x7fffff00u; q1 = (uint32_t)r1 & 0x7fffff00u; q2 = (uint32_t)r2 & 0x7fffff00u; q3 = (uint32_t)r3 & 0x7fffff00u;
+        V.q0 = (uint32_t)r0 & 0x7fffff00u; V.q1 = (uint32_t)r1 & 0x7fffff00u; V.q2 = (uint32_t)r2 & 0x7fffff00u; V.q3 = (uint32_t)r3 & 0x7fffff00u;
     }
-    uint32_t tail = lq_t + added;
     wmask m0 = H0 & N0, m1 = H1 & N1, m2 = H2 & N2, m3 = H3 & N3;         // leaf children that are hit
     wmask i0 = H0 & ~N0, i1 = H1 & ~N1, i2 = H2 & ~N2, i3 = H3 & ~N3;     // inner children that are hit
     if (CHECK != 0) {
@@ -911,11 +920,9 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     }
     const wmask EFF = CHECK == 1 ? EN & ~*voided : EN; // the lanes whose visit counts
     if (STATS && lanes(EFF)) tc.inner++;
-    leafq_push_all(S, lanes(m0), m0, q0 | id, tail);
-    leafq_push_all(S, lanes(m1), m1, q1 | id, tail);
-    leafq_push_all(S, lanes(m2), m2, q2 | id, tail);
-    leafq_push_all(S, lanes(m3), m3, q3 | id, tail);
-    added = tail - lq_t;
+    V.m0 = m0; V.m1 = m1; V.m2 = m2; V.m3 = m3;
+    V.tail = lq_t + added;
+    added += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
     n_leaf = add_mask(add_mask(add_mask(add_mask(n_leaf, m0), m1), m2), m3);
     any_leaf |= (m0 | m1) | (m2 | m3);
     // The nearest inner child that is hit goes to the front, by a tournament (0,1)(2,3)(winners) on (hit, distance): b beats a iff b is hit and
@@ -925,39 +932,50 @@ __device__ __forceinline__ wmask inner4_step_dec(const DevScene& sc, LDS& S, con
     // The order of the visits is the one of round 5: the result cannot depend on it (crt_trace.h), the any-hit rays' visit counts do.
     const wmask S01 = i1 & (bal(t1 < t0) | ~i0), S23 = i3 & (bal(t3 < t2) | ~i2);
     const float tA = lanes(S01) ? t1 : t0, tC = lanes(S23) ? t3 : t2;
-    const int rA = lanes(S01) ? r1 : r0, rB = lanes(S01) ? r0 : r1, rC = lanes(S23) ? r3 : r2, rD = lanes(S23) ? r2 : r3;
-    const wmask IA = i0 | i1, IB = i0 & i1, IC = i2 | i3, ID = i2 & i3;
+    const int rA = lanes(S01) ? r1 : r0, rC = lanes(S23) ? r3 : r2;
+    V.rb = lanes(S01) ? r0 : r1; V.rd = lanes(S23) ? r2 : r3;
+    const wmask IA = i0 | i1, IC = i2 | i3;
+    V.pb = i0 & i1; V.pd = i2 & i3;
     const wmask S02 = IC & (bal(tC < tA) | ~IA);
-    const int rF = lanes(S02) ? rC : rA, rG = lanes(S02) ? rA : rC;
-    const wmask IF = IA | IC, IG = IA & IC;
+    const int rF = lanes(S02) ? rC : rA;
+    V.rg = lanes(S02) ? rA : rC;
+    const wmask IF = IA | IC;
+    V.pg = IA & IC;
     // pushed: the loser of (2,3), then the loser of the final, then the loser of (0,1) -- which is popped first
-    const int l3_ = sp, l2_ = add_mask(l3_, ID), l1_ = add_mask(l2_, IG), sp_new = add_mask(l1_, IB);
+    V.l3 = sp; V.l2 = add_mask(V.l3, V.pd); V.l1 = add_mask(V.l2, V.pg); V.sp_new = add_mask(V.l1, V.pb);
     constexpr int LV = LDS::LV;
-    typedef typename LDS::stk_t stk_t;
-    if (lanes(ID & bal(l3_ < LV))) S.stk[l3_][id] = (stk_t)rD;
-    if (lanes(IG & bal(l2_ < LV))) S.stk[l2_][id] = (stk_t)rG;
-    if (lanes(IB & bal(l1_ < LV))) S.stk[l1_][id] = (stk_t)rB;
-    if (bal((sp_new > l3_) & (sp_new > LV))) {
-        if (lanes(ID & bal(l3_ >= LV))) M.spill[(size_t)(l3_ - LV) * M.M.spill_stride + g] = rD;
-        if (lanes(IG & bal(l2_ >= LV))) M.spill[(size_t)(l2_ - LV) * M.M.spill_stride + g] = rG;
-        if (lanes(IB & bal(l1_ >= LV))) M.spill[(size_t)(l1_ - LV) * M.M.spill_stride + g] = rB;
-    }
-    if (STATS && (uint32_t)sp_new > max_sp) max_sp = (uint32_t)sp_new;
-    // the nearest inner child next; without one (nothing was pushed either: the top is the one read above) the stack's top, or the end
+    if (STATS && (uint32_t)V.sp_new > max_sp) max_sp = (uint32_t)V.sp_new;
+    // the nearest inner child next; without one (nothing was pushed either: the top is the one read when the visit began) the stack's top, or the end
     const wmask NF = EFF & ~IF;
-    const wmask POP = NF & bal(sp_new > 0);
+    const wmask POP = NF & bal(V.sp_new > 0);
     const wmask OVER = NF & ~POP;
     const int nref = lanes(IF) ? rF : top;
     ref = lanes(IF | POP) ? nref : ref;
-    sp = sub_mask(sp_new, POP);
-#ifdef CRT_X_EXTRA_LOADS
-    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) asm volatile("" :: "v"(xl_[k_]));
-#endif
+    sp = sub_mask(V.sp_new, POP);
     const wmask DEEP = POP & bal(sp >= LV); // (of the new depth -- the carry instruction's own result: the compiler shares a compare of sp_new with the push block's and sends it through a vector register)
     if (DEEP) {
         if (lanes(DEEP)) ref = M.spill[(size_t)(sp - LV) * M.M.spill_stride + g];
     }
     return OVER;
+}
+template <class LDS>
+__device__ __forceinline__ void visit_back(LDS& S, const MParams3& M, const uint32_t id, const uint32_t g, const Visit4& V)
+{
+    uint32_t tail = V.tail;
+    leafq_push_all(S, lanes(V.m0), V.m0, V.q0 | id, tail);
+    leafq_push_all(S, lanes(V.m1), V.m1, V.q1 | id, tail);
+    leafq_push_all(S, lanes(V.m2), V.m2, V.q2 | id, tail);
+    leafq_push_all(S, lanes(V.m3), V.m3, V.q3 | id, tail);
+    constexpr int LV = LDS::LV;
+    typedef typename LDS::stk_t stk_t;
+    if (lanes(V.pd & bal(V.l3 < LV))) S.stk[V.l3][id] = (stk_t)V.rd;
+    if (lanes(V.pg & bal(V.l2 < LV))) S.stk[V.l2][id] = (stk_t)V.rg;
+    if (lanes(V.pb & bal(V.l1 < LV))) S.stk[V.l1][id] = (stk_t)V.rb;
+    if (bal((V.sp_new > V.l3) & (V.sp_new > LV))) {
+        if (lanes(V.pd & bal(V.l3 >= LV))) M.spill[(size_t)(V.l3 - LV) * M.M.spill_stride + g] = V.rd;
+        if (lanes(V.pg & bal(V.l2 >= LV))) M.spill[(size_t)(V.l2 - LV) * M.M.spill_stride + g] = V.rg;
+        if (lanes(V.pb & bal(V.l1 >= LV))) M.spill[(size_t)(V.l1 - LV) * M.M.spill_stride + g] = V.rb;
+    }
 }
 
 // One step at a node of a 2-wide tree: the reference topology (CRT_TRAVERSAL_REFERENCE: reference box arithmetic, reference
@@ -1317,27 +1335,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const uint32_t lq_used = (lq_t - lq_h) + (MAY_EXACT ? 64u : 0u);
                     const uint32_t lq_free = lq_used < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used : 0u;
                     // (MAY_EXACT: the rays of the reference-arithmetic path append one entry each below, outside that count)
-                    DONE |= inner4_step_dec<STATS, LDS3, 1, IMPL>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, GO & ~EX, lq_free, nullptr, &VOID);
-                    if (STATS && lanes(GO & ~EX & VOID)) dg_ov[0]++;
+                    Visit4 V1, V2;
+                    const wmask EN1 = GO & ~EX;
+                    node_load<IMPL>(sc, ref, EN1, dir, V1);
+#ifdef CRT_X_EXTRA_LOADS /* sensitivity experiment (round 6): N more loads per first visit from the node's own line, issued with the others, consumed at the end of the step */
+                    float xl_[CRT_X_EXTRA_LOADS];
+                    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) {
+                        uint32_t off_ = lanes(EN1) ? (uint32_t)ref * (IMPL ? (uint32_t)(NODE4I_F4 * 16) : 128u) : 0u;
+                        asm volatile("" : "+v"(off_));
+#if defined(CRT_X_EXTRA_UNIFORM)
+                        off_ &= 0u; /* every lane the same address */
+#endif
+                        xl_[k_] = *(const float*)(((const char*)(IMPL ? sc.nodes4i : sc.nodes4) + off_) + 80);
+                    }
+#endif
+                    const int top1 = stack_top_ahead(S, id, sp, LDS3::LV);
+                    DONE |= visit_front<STATS, LDS3, 1, IMPL>(sc, M3, g, dir, R, V1, top1, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN1, lq_free, nullptr, &VOID);
+                    if (STATS && lanes(EN1 & VOID)) dg_ov[0]++;
                     // A SECOND NODE in the same step for the rays that go on, their record still in registers (in the form
                     // this pool allows: with the leaves decoupled a ray that is not finished always has an inner node next).  Taken while at
                     // least VISIT2_MIN lanes go on; its leaf entries are counted before anything is written, and if the queue cannot take
                     // them the visit is dropped.  C2 82.7 -> 81.7 ms, veach-mis spp 256
                     // 81.8 -> 80.3 (40 .. 52: the same; 16 / 32: 82.6 / 82.1 and 80.8 / 80.6; as a loop, or three / four visits: worse).
-                    if (!MAY_EXACT) {
+                    // Round 6: its node is fetched BEFORE the first visit's appends and pushes are written (node_load / visit_back).
 #ifndef CRT_VISIT2_MIN
 #define CRT_VISIT2_MIN 44
 #endif
-                        constexpr int VISIT2_MIN = CRT_VISIT2_MIN;
-                        const wmask EN2 = ON & ~DONE;
-                        if ((int)__popcll(EN2) >= VISIT2_MIN) {
-                            const uint32_t lq_used2 = (lq_t + added) - lq_h;
-                            const uint32_t cap_left = lq_used2 < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used2 : 0u;
-                            bool bailed = false;
-                            DONE |= inner4_step_dec<STATS, LDS3, 2, IMPL>(sc, S, M3, id, g, dir, R, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN2, cap_left, &bailed);
-                            if (STATS && bailed && lanes(EN2)) dg_ov[1]++;
-                        }
+                    constexpr int VISIT2_MIN = CRT_VISIT2_MIN;
+                    const wmask EN2 = ON & ~DONE;
+                    const bool second = !MAY_EXACT && (int)__popcll(EN2) >= VISIT2_MIN;
+                    if (second) node_load<IMPL>(sc, ref, EN2, dir, V2);
+                    visit_back(S, M3, id, g, V1);
+                    if (second) {
+                        const uint32_t lq_used2 = (lq_t + added) - lq_h;
+                        const uint32_t cap_left = lq_used2 < (uint32_t)LEAFQ_CAP ? (uint32_t)LEAFQ_CAP - lq_used2 : 0u;
+                        bool bailed = false;
+                        const int top2 = stack_top_ahead(S, id, sp, LDS3::LV);
+                        DONE |= visit_front<STATS, LDS3, 2, IMPL>(sc, M3, g, dir, R, V2, top2, ref, sp, tc, max_sp, lq_t, added, ANY, n_leaf, EN2, cap_left, &bailed);
+                        if (!bailed) visit_back(S, M3, id, g, V2);
+                        if (STATS && bailed && lanes(EN2)) dg_ov[1]++;
                     }
+#ifdef CRT_X_EXTRA_LOADS
+                    for (int k_ = 0; k_ < CRT_X_EXTRA_LOADS; k_++) asm volatile("" :: "v"(xl_[k_]));
+#endif
                 }
                 if (MAY_EXACT) {
                     const wmask GX = GO & EX;
@@ -1400,6 +1440,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 const float4 qa = S.A[id], qb = S.B[id];
                 const F3 o = f3(qa.x, qa.y, qa.z), d = f3(qb.x, qb.y, qb.z);
                 const float Tl = qa.w;
+                // The entry leaves the ray's count of entries in flight NOW (round 6): the returning LDS atomic's round trip hides behind the
+                // record's loads instead of standing alone at the end of the step.  Every minimum of this step is in LDS before the step ends,
+                // and nothing reads a ray's answer before the step that routes it has ended -- the order of the two atomics inside a step is free.
+                if (lanes(ON)) t_flags = __hip_atomic_fetch_sub(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 uint32_t rec = item >> 8;
                 // the leaf's candidate: the first of its triangles among equal distances (ascending index, strict <: DeviceBVH.cuh:34-41)
                 bool have = false;
@@ -1434,8 +1478,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     // across leaves: the smaller distance, among equal ones the larger leaf start (crt_trace.h) = the larger triangle index, as
                     // the leaves own disjoint ascending ranges -- one 64-bit minimum over (bits(t), ~triangle); t > EPSILON > 0, so its bits order as it does
                     if (have) __hip_atomic_fetch_min(&S.best[id], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)(uint32_t)~bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const uint32_t od = __hip_atomic_fetch_sub(&S.D[id], 1u << RD_PEND_SHIFT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    t_flags = od;
                 }
                 COMP = bal((t_flags & (RD_PEND_MASK | RD_FIN)) == ((1u << RD_PEND_SHIFT) | RD_FIN)); // the last entry of a ray whose walk is over (t_flags is 0 beyond the batch)
             }
