@@ -602,6 +602,24 @@ __device__ __forceinline__ void slab_quad_pruned(const float4 nx, const float4 f
 __device__ __forceinline__ v2f pk_submul_ll(const v2f p, const v2f o, const v2f i) { CRT_PK_SUBMUL_IMPL(0, 0) }
 __device__ __forceinline__ v2f pk_submul_hh(const v2f p, const v2f o, const v2f i) { CRT_PK_SUBMUL_IMPL(1, 1) }
 #undef CRT_PK_SUBMUL_IMPL
+// (pair.H, pair.H) * x and (pair.H, pair.H) - x: a ray's scalar against two triangles' values, the scalar picked from an aligned pair by the
+// instruction (tri_pair).  The products and differences are the plain IEEE ones of the scalar form.
+template <int H>
+__device__ __forceinline__ v2f pk_bmul(const v2f pair, const v2f x)
+{
+    v2f d_;
+    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d_) : "v"(pair), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d_) : "v"(pair), "v"(x));
+    return d_;
+}
+template <int H>
+__device__ __forceinline__ v2f pk_bsub(const v2f pair, const v2f x)
+{
+    v2f d_;
+    if (H == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d_) : "v"(pair), "v"(x));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d_) : "v"(pair), "v"(x));
+    return d_;
+}
 // the ray as the 4-wide step keeps it: (o.x, o.y), (o.z, -) and (1/d.x, 1/d.y), (1/d.z, -) in aligned register pairs
 struct RayPk { v2f oxy, oz, ixy, iz; };
 
@@ -629,15 +647,17 @@ __device__ __forceinline__ void slab_quad_hits(const float4 nx, const float4 fx,
 
 // The two triangles of a leaf record at once: Moeller-Trumbore exactly as DeviceTriangle.cuh:39-56 + inside() :58-65 +
 // the t > EPSILON filter of DeviceBVHNode::hit (DeviceBVH.cuh:37); lane .x = first triangle, .y = second.
-__device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4 g4, const F3 o, const F3 d,
-                                         bool& a0, bool& a1, float& t0, float& t1)
+// (round 6: o and d arrive as the aligned register pairs their LDS records are read into -- (o.x, o.y), (o.z, -), (d.x, d.y), (d.z, -) -- and the
+// twelve instructions that take one of their components against both triangles pick it with operand selects: no (x, x) pair is built)
+__device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const float4 g4, const v2f oxy, const v2f oz,
+                                         const v2f dxy, const v2f dz, bool& a0, bool& a1, float& t0, float& t1)
 {
     const v2f v1x = v2(g0.x, g0.y), v1y = v2(g0.z, g0.w), v1z = v2(g1.x, g1.y);
     const v2f e1x = v2(g1.z, g1.w), e1y = v2(g2.x, g2.y), e1z = v2(g2.z, g2.w);
     const v2f e2x = v2(g3.x, g3.y), e2y = v2(g3.z, g3.w), e2z = v2(g4.x, g4.y);
-    const v2f sx = v2s(o.x) - v1x, sy = v2s(o.y) - v1y, sz = v2s(o.z) - v1z;
+    const v2f sx = pk_bsub<0>(oxy, v1x), sy = pk_bsub<1>(oxy, v1y), sz = pk_bsub<0>(oz, v1z);
     // s1 = d x e2, s2 = s x e1 (OrthoMethods.h:106-108)
-    const v2f s1x = v2s(d.y) * e2z - v2s(d.z) * e2y, s1y = v2s(d.z) * e2x - v2s(d.x) * e2z, s1z = v2s(d.x) * e2y - v2s(d.y) * e2x;
+    const v2f s1x = pk_bmul<1>(dxy, e2z) - pk_bmul<0>(dz, e2y), s1y = pk_bmul<0>(dz, e2x) - pk_bmul<0>(dxy, e2z), s1z = pk_bmul<0>(dxy, e2y) - pk_bmul<1>(dxy, e2x);
     const v2f s2x = sy * e1z - sz * e1y, s2y = sz * e1x - sx * e1z, s2z = sx * e1y - sy * e1x;
     const v2f det = s1x * e1x + (s1y * e1y + s1z * e1z);
     v2f rcp; // 1 / det (DeviceTriangle.cuh:47), see rcp_ieee
@@ -652,7 +672,7 @@ __device__ __forceinline__ void tri_pair(const float4 g0, const float4 g1, const
         }
     }
     const v2f beta = (s1x * sx + (s1y * sy + s1z * sz)) * rcp;
-    const v2f gamma = (s2x * v2s(d.x) + (s2y * v2s(d.y) + s2z * v2s(d.z))) * rcp;
+    const v2f gamma = (pk_bmul<0>(dxy, s2x) + (pk_bmul<1>(dxy, s2y) + pk_bmul<0>(dz, s2z))) * rcp;
     const v2f t = (s2x * e2x + (s2y * e2y + s2z * e2z)) * rcp;
     const v2f alpha = v2s(1.0f) - beta - gamma;
     // inside(): 0 < alpha, beta, gamma < 1, each comparison false for a NaN.  v_minimum3_f32 / v_maximum3_f32 (IEEE 754-2019
@@ -1243,7 +1263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const bool two = left > 1;
                     bool a0, a1;
                     float t0, t1;
-                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
+                    tri_pair(g0, g1, g2, g3, g4, v2(qa.x, qa.y), v2(qa.z, qa.w), v2(qb.x, qb.y), v2(qb.z, qb.w), a0, a1, t0, t1);
                     a1 = a1 && two;
                     if (STATS) { tc.tests += two ? 2u : 1u; }
                     if (any_hit) {
@@ -1430,6 +1450,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
             const int take = min(64, (int)(lq_t - lq_h));
             if (STATS) { dg_b[PH3_LEAF]++; dg_l[PH3_LEAF] += (uint32_t)take; }
             const wmask ON = bal(lane < take);
+            // (fetching these entries and their records from the inner step before this one -- they are known when the queue held 64 before it --
+            // was measured in round 6: the values arrive in other registers than the step's own loads use, 20 copies and a full wait: +1.3 %)
             const uint32_t item_raw = S.leafq[(lq_h + (uint32_t)lane) & (uint32_t)(LEAFQ_CAP - 1)];
             lq_h += (uint32_t)take;
             const uint32_t item = lanes(ON) ? item_raw : 0u;
@@ -1460,7 +1482,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                     const bool two = left > 1;
                     bool a0, a1;
                     float t0, t1;
-                    tri_pair(g0, g1, g2, g3, g4, o, d, a0, a1, t0, t1);
+                    tri_pair(g0, g1, g2, g3, g4, v2(qa.x, qa.y), v2(qa.z, qa.w), v2(qb.x, qb.y), v2(qb.z, qb.w), a0, a1, t0, t1);
                     if (STATS && lanes(ON)) { tc.tests += two ? 2u : 1u; }
                     // (Tl - t > EPSILON: the visibility test of an any-hit ray, Render.cuh:19-27; always true for Tl = +inf and a finite t,
                     // false for t = +inf, which the reference's t < best.t rejects as well)

@@ -18,7 +18,7 @@ ap.add_argument("--seeds", type=int, nargs="+", default=[0])
 ap.add_argument("--out", default=None)
 ap.add_argument("--mode", default="fast", choices=["fast", "exact"])
 ap.add_argument("--only", type=int, nargs="*", default=None, help="ranks to render (default: all)")
-ap.add_argument("--forms", default="default", help="comma list of pool forms the tested mode is rendered with: default, coupled (CRT_DEC=0), decoupled (CRT_DEC=1)")
+ap.add_argument("--forms", default="default", help="comma list of pool forms the tested mode is rendered with: default, coupled (CRT_DEC=0), decoupled (CRT_DEC=1), refs (decoupled on the tree WITH its rows of refs: CRT_DEC=1 CRT_IMPL=0)")
 a = ap.parse_args()
 t = crt.Task(os.path.join(ROOT, "scenes", a.scene, "config.json"), base_dir=ROOT)
 sc = crt.Scene.from_task(t, a.width, a.height)
@@ -37,10 +37,13 @@ for seed in a.seeds:
         runs = [("fast" if f == forms[0] else "fast_" + f, crt.TRAVERSAL_EXACT if a.mode == "exact" else crt.TRAVERSAL_FAST, f) for f in forms]
         for name, trav, form in runs + [("ref", crt.TRAVERSAL_REFERENCE, "default")]:
             os.environ.pop("CRT_DEC", None)
+            os.environ.pop("CRT_IMPL", None)
             if form == "coupled":
                 os.environ["CRT_DEC"] = "0"
             elif form == "decoupled":
                 os.environ["CRT_DEC"] = "1"
+            elif form == "refs":
+                os.environ["CRT_DEC"] = "1"; os.environ["CRT_IMPL"] = "0"
             r.traversal = trav
             buf = np.zeros((slots, 3), dtype=np.uint8)
             mean = np.zeros((slots, 3), dtype=np.float32)
