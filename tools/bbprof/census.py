@@ -44,7 +44,7 @@ def main():
         # what the vector instructions are: intersection arithmetic (the box and triangle tests with their reciprocals, minima and
         # maxima), the rest of the two traversal steps (rings, records, stacks, routing), the path logic
         ARITH = ("tri_pair", "slab_quad_pruned", "slab_quad_hits", "slab_pair_hits", "slab_pair", "slab_pair_pruned", "rcp_short", "rcp_short_ok", "rcp_short_ok2", "rcp_short_ok3", "rcp_ieee",
-                 "inv3_exact", "fmin3", "fmax3", "finite3")
+                 "inv3_exact", "fmin3", "fmax3", "finite3", "pk_submul_ll", "pk_submul_hh", "pk_bmul", "pk_bsub")  # (round 6: the packed instructions written with operand selects)
         trav = ("inner", "leaf", "inner_ex", "leaf_ex")
         arith = sum(e["dyn_valu"] for e in r["by_phase_function"] if e["phase"] in trav and e["function"] in ARITH)
         trav_all = sum(e["dyn_valu"] for e in r["by_phase_function"] if e["phase"] in trav) + r["by_phase"].get("other", {}).get("dyn_valu", 0)
