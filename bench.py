@@ -470,7 +470,7 @@ def main_rank(args):
         barrier()
         elapsed = time.perf_counter() - t0
     # device memory of the per-path radiance of the timed frames on this rank (crt_radiance_storage): one 16-byte value per path of a
-    # chunk by default; CRT_FLAG_BOUNDED_RADIANCE would make it a ring of samples
+    # chunk by default; CRT_FLAG_BOUNDED_RADIANCE would make it a ring of samples (docs/experiments.md section 9)
     radiance_storage = None
     if not multi:
         try:
@@ -607,7 +607,7 @@ def main_rank(args):
                           "kernel_ms": round(st_all["kernel_ms"], 3)}
 
         # ---- the same frame in the OTHER of the two production modes, timed and compared with the frame of the timed steps:
-        #      CRT_TRAVERSAL_EXACT (default; provably the reference's frame) against CRT_TRAVERSAL_FAST (+ distance pruning) ----
+        #      CRT_TRAVERSAL_EXACT (default; provably the reference's frame; docs/experiments.md 4.3) against CRT_TRAVERSAL_FAST (+ distance pruning) ----
         other_mode = None
         other_name = None
         if single and not multi and trav in (crt.TRAVERSAL_FAST, crt.TRAVERSAL_EXACT):

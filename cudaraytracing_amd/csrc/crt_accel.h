@@ -193,7 +193,7 @@ inline int build_sah(std::vector<Prim>& prims, std::vector<Node>& nodes, int32_t
 // ancestors grow by), found by a best-first search with the induced cost as lower bound.  The old position is among the candidates,
 // so the summed area of the inner nodes never grows.  The tree stays a tree over the same leaves, so results cannot change; what
 // changes is the number of nodes and leaves a ray meets (one pass, moves that save at least half: cornell-box stand-in 5.04 -> 4.31
-// inner and 3.93 -> 3.68 leaf visits per ray, frame - 5.4 %; veach-mis - 1.7 %; the 102 412-triangle variant - 3.9 %).
+// inner and 3.93 -> 3.68 leaf visits per ray, frame - 5.4 %; veach-mis - 1.7 %; the 102 412-triangle variant - 3.9 %; docs/experiments.md 7).
 // Returns the new depth; nodes come back in breadth-first order, root = 0.
 inline int optimize_sah_serial(std::vector<Node>& nodes, int passes)
 {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const AParams A)
         const float fspp = (float)A.spp;
         for (uint32_t s = 0; s < A.chunk_samples; s++) { // temp_color += L / spp, in sample order (Render.cuh:348)
             // (agent-scope loads: the radiance was written by the launch before this one, from other XCDs -- the same kind of hand-off as
-            // k_order_items -> k_mega3, whose plain loads were seen to return what an earlier kernel had left at the address)
+            // k_order_items -> k_mega3, whose plain loads were seen to return what an earlier kernel had left at the address, docs/experiments.md 6)
             const float* lp = (const float*)&A.L[(uint64_t)s * A.nslots + slot];
 #ifdef CRT_ACCUM_PLAIN
             const float lx = lp[0], ly = lp[1], lz = lp[2];

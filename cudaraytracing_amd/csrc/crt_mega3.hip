@@ -464,7 +464,7 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
                 const uint32_t wlo_ = shi_ - min(P.order_window, shi_ - slo_);
                 // (agent-scope load, as k_order_items' stores: with plain accesses the FIRST frame of a render created after other renders of
                 // the process came out with 10 - 400 work items of the 589 824 of a 96 x 64 x 96 frame never run -- their list entries read as
-                // what an earlier kernel had left at the address -- in half of the runs once the launches' timing had changed)
+                // what an earlier kernel had left at the address -- in half of the runs once the launches' timing had changed; docs/experiments.md 6)
 #if defined(CRT_HANDOFF_PLAIN) || defined(CRT_HANDOFF_PLAIN_LOAD) /* experiment builds only (tools/handoff_ab.sh): the accesses as they were */
                 if (item >= wlo_) item = ((CRT_GAS const unsigned int*)P.item_list)[sh_ * P.order_window + (item - wlo_)];
 #else

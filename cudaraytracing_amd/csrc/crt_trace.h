@@ -57,7 +57,7 @@ __device__ __forceinline__ bool slab_test(float4 lo, float4 hi, const RayT& r, b
 // (tools/soak_fast_vs_reference.py) finds 2 lost visibility rays in 3.66e11 rays of veach-mis (cos = 5e-6 / 3e-6 against a small
 // sphere triangle; t lands 0.045 / 0.035 in front of the leaf box, 3.5 / 7.7 x the slack) and 0 in 3.4e11 of cornell-box; the
 // margin histogram of tools/margin_hist.py shows a tail ~ s^-0.7 on veach-mis (factor 1e-3: a fifth of the events for +8.5 % frame
-// time) and no tail at all on cornell-box.  DESIGN.md section 4.3 has the numbers; include/crt.h states the contract; the lost
+// time) and no tail at all on cornell-box.  DESIGN.md section 4; docs/experiments.md 4.3 has the numbers; include/crt.h states the contract; the lost
 // rays are known answers in tests/test_adversarial_traversal.py.  Rays with a zero direction component get an infinite bound.
 #ifndef CRT_PRUNE_REL
 #define CRT_PRUNE_REL 1.0e-4f

@@ -106,7 +106,7 @@ def render_sharded(render, eye, inv_view, fov_y, width, height, rank, world, dev
 
 class FramePipeline:
     """Two frames in flight per rank.  Every launch of the persistent render kernel ends with its waves running their private
-    path pools dry (about 2 ms, DESIGN.md "Multi-GPU"): with one frame at a time that tail is idle GPU, 1.7 % of a C2 frame on
+    path pools dry (about 2 ms): with one frame at a time that tail is idle GPU, 1.7 % of a C2 frame on
     one GPU and 12 % of a rank's share on eight.  The pipeline alternates two device replicas of the scene (two crt_scene handles:
     path pools, per-path radiance and accumulators are per handle) on two HIP streams, so the workgroups of frame i+1 are
     dispatched into the compute units as the waves of frame i retire; the tile gather of a frame is enqueued on the frame's

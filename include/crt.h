@@ -106,7 +106,7 @@ typedef struct {
 enum {
     CRT_TRAVERSAL_EXACT = 0,     /* THE DEFAULT (a zeroed crt_params): the 4-wide tree over the reference's leaves, nearest child first, any-hit
                                     visibility rays, zero-contribution samples answered without traversal -- every step of it provably
-                                    result-neutral, so the frame is REFERENCE's bit for bit (soak: 3.9e11 rays of
+                                    result-neutral (docs/experiments.md 4.3), so the frame is REFERENCE's bit for bit (soak: 3.9e11 rays of
                                     full-size frames, 0 pixel slots differ) at 1/4 .. 1/6 of REFERENCE's time */
     CRT_TRAVERSAL_REFERENCE = 1, /* exhaustive traversal in the reference's visit order (DeviceBVH.cuh:128-170) */
     CRT_TRAVERSAL_FAST = 2       /* CRT_TRAVERSAL_EXACT plus distance pruning: skip a box entered beyond t_ref + 0.1 % + 1e-3 + 1e-4 x reach x steep
@@ -116,7 +116,7 @@ enum {
                                     the reference has no determinant threshold).  MEASURED (tools/soak_fast_vs_reference.py,
                                     profiles/r02_soak_fast_vs_reference.jsonl): 2 rays in 3.66e11 on full 1920x1080x4096 veach-mis frames
                                     (tessellated spheres; each changes one next-event sample: the last bit of one pixel), 0 in 3.4e11 on full
-                                    3840x2160x256 cornell-box frames; a larger slack only thins them out.
+                                    3840x2160x256 cornell-box frames; a larger slack only thins them out (docs/experiments.md 4.3).
                                     Bit-identical to REFERENCE on every frame and probe of the test-suite (two lost rays are kept as known
                                     answers in tests/test_adversarial_traversal.py); bench.py times it beside the default and re-checks a
                                     slice of the benchmark frame against REFERENCE in every run */
@@ -129,7 +129,7 @@ enum {
     CRT_FLAG_FORCE_EXACT = 4u,   /* test hook: treat every ray of CRT_TRAVERSAL_FAST as one with non-finite operands (reference
                                     box arithmetic on the reference topology, still pruned / any-hit); results are unchanged */
     CRT_FLAG_BOUNDED_RADIANCE = 16u /* keep the radiance of a WINDOW of samples instead of one value per path: the frame's sum c += L_k / spp
-                                    (Render.cuh:348) is made in sample order inside the launch ("commit ring"), the
+                                    (Render.cuh:348) is made in sample order inside the launch ("commit ring", docs/experiments.md section 9), the
                                     whole sample range is one launch whatever its size, and the handle needs 16 B x pixels x 32 ... 64
                                     samples (245 MB for 800x600) instead of 16 B per path (3.9 GB for 800x600 spp 512; 17 GB per 2^30 paths).
                                     Same bits.  Costs time (800x600 spp 512: 167 ms instead of 93): off by default -- memory is what this

@@ -1,7 +1,7 @@
 """Run in a child process by test_first_frame.py (and by tools/r05/handoff_ab.sh with CRT_LIB_PATH = an experiment build): first frames of
 many short-lived Render objects of EQUAL size that alternate between two scenes and between the default path and the commit ring, every new
 device allocation pre-filled with 0xFF bytes (CRT_DEBUG_FILL=255: NaN radiance, out-of-range work items), each frame against the oracle.
-What it is after: a kernel-to-kernel hand-off that reads what a previous owner of the address left there -- the allocator
+What it is after: a kernel-to-kernel hand-off that reads what a previous owner of the address left there (docs/experiments.md 6) -- the allocator
 hands a freed buffer to the next Render of the same size, so the stale copy and the fresh one share an address.  Prints one JSON line."""
 import json
 import os

@@ -388,7 +388,7 @@ def test_visibility_queries(name):
 # triangle of a light sphere (cos = 5e-6 / 3e-6), whose Moeller-Trumbore distance lands 0.045 / 0.035 in front of the triangle's own
 # leaf box -- 3.5 / 7.7 times the pruning slack.  No slack factor removes such events (tools/margin_hist.py: the number of answers
 # lying more than s x reach x steep in front of their box falls only as s^-0.7), so the contract of CRT_TRAVERSAL_FAST is a measured
-# rate (2 such rays in 3.7e11 on this scene), CRT_TRAVERSAL_REFERENCE is the exact mode, and these two rays
+# rate (docs/experiments.md 4.3: 2 such rays in 3.7e11 on this scene), CRT_TRAVERSAL_REFERENCE is the exact mode, and these two rays
 # are kept as known answers: REFERENCE must block them; FAST is reported (xfail) when it does not.
 # (origin, Ray direction, t_to_light) as float bits; found by tools/soak_fast_vs_reference.py, isolated by tools/diff_fast_reference.py.
 _LOST_VISIBILITY_RAYS = [
@@ -420,7 +420,7 @@ def test_the_c5_visibility_rays_that_pruning_loses(bits, blocker):
         assert tri_f[0] == blocker and util.bits(tt_f)[0] == util.bits(tt)[0]
         blk, btri = r.blocked(o, d, lim, traversal=crt.TRAVERSAL_FAST | RAW)
         if not blk[0]:
-            pytest.xfail("documented: the blocker's box is entered beyond prune_bound(t_to_light) (DESIGN.md section 4.3)")
+            pytest.xfail("documented: the blocker's box is entered beyond prune_bound(t_to_light) (DESIGN.md section 4; docs/experiments.md 4.3)")
         assert btri[0] == blocker
     finally:
         r.free()

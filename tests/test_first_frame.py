@@ -3,7 +3,7 @@ render one frame per Render object or the same frame again:
   * the FIRST frame of a Render created after other renders of the process -- its device buffers are whatever the allocator hands back, and
     the caches may still hold lines of their previous owners.  Round 4 found k_mega3 reading entries of the work-item list (k_order_items)
     as an earlier kernel had left them: 10 - 400 of 589 824 work items never ran, in half of such first frames, once the launches' timing
-    had changed (the list is now written and read with agent-scope accesses; DESIGN.md 6);
+    had changed (the list is now written and read with agent-scope accesses; docs/experiments.md 6);
   * frames whose content differs from the frame before in the same Render (seed, camera, size): a stale line of the previous frame's
     radiance or path state would show, where a repeated frame hides it.
 Every frame against the CPU oracle, bit for bit."""
