@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <atomic>
 #include <condition_variable>
@@ -329,34 +330,34 @@ inline int optimize_sah_serial(std::vector<Node>& nodes, int passes)
     return md;
 }
 
-// The pass as crt_scene_create runs it (round 5): the same moves found SPECULATIVELY on several threads.  Of the ~49 000
-// nodes of the stand-in's tree 300 move; the time goes into the searches that end where they began.  A search never changes the tree: it
-// works on the tree as it is, with the node's removal emulated (the boxes along its root path shrunk in a thread-local overlay), so the
-// searches of a block of nodes run in parallel on a frozen tree.  The block is then applied in order: a node that stays only has its parent's
-// children put in the order (sibling, node) the serial pass leaves them in -- no box changes --; a node that moves is taken out and put in for
-// real, every node whose box or links change is stamped, and a later node of the block whose search READ a stamped node is searched again on
-// the tree as it then is.  Each result is therefore what a serial execution of this same algorithm produces: the output does not depend on
-// the number of threads or on timing.  (Against optimize_sah_serial the search pushes a node's children in the order of their ids instead of
-// their child slots, so that the sibling order the pass itself normalises cannot steer ties: the two forms may resolve exact ties between
-// equally good positions differently -- any tree over the reference's leaves renders the same frame.)
+// The pass as crt_scene_create runs it (round 6): the searches of a BLOCK of nodes run on the tree AS IT IS AT THE START OF
+// THE BLOCK, in parallel; their moves are then applied in order.  Of the ~49 000 nodes of the stand-in's tree 300 move: the time goes into the
+// searches that end where they began, and those never change the tree -- a search works with the node's removal emulated (the boxes along
+// its root path shrunk in a thread-local overlay).  A move found on the block's tree is applied to the tree as earlier moves of the block left
+// it, provided it is still a move of a tree (the node still has a grandparent, the place is not its own parent, sibling or subtree); its gain
+// was priced on the block's tree, the way the parallel reinsertion of Meister & Bittner 2018 prices a whole pass.  The block size is a
+// constant, so the result depends neither on the number of threads nor on timing; it is not the tree of optimize_sah_serial (whose every
+// search sees every earlier move), but one of the same quality: summed inner area 1.7009e7 -> see tests/test_sah_opt.py, and the frame times
+// of docs/experiments.md 6.10.  (Round 5's form reproduced the serial pass exactly by recording what every search read and repeating the
+// stale ones: the bookkeeping cost as much as the searches, 21 ms on eight threads against 32 serial.)
+#ifndef CRT_SAH_HEAD
+#define CRT_SAH_HEAD 64
+#endif
 inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
 {
     const int A = (int)nodes.size();
     if (A < 3 || passes <= 0) return optimize_sah_serial(nodes, passes);
     if (n_threads <= 0) {
-        // The CPUs this process may RUN on (its affinity mask: a cgroup's cpuset or taskset shows here; hardware_concurrency() counts the
-        // machine's) decide: the speculative form pays only from four threads on (measured: 32 ms serial, 43 / 36 / 28 / 21 ms on 1 / 2 / 4 / 8
-        // threads, profiles/r05_experiments/sah_opt_threads.txt), and its helpers spin -- with fewer CPUs, or when eight ranks of one node
-        // build their trees at once on a share of the cores each, the serial form is the faster one.
+        // the CPUs this process may RUN on (its affinity mask: a cgroup's cpuset or taskset shows here; hardware_concurrency() counts the
+        // machine's); the helpers spin between blocks, so never more threads than that
         unsigned usable = std::max(1u, std::thread::hardware_concurrency());
 #if defined(__linux__)
         cpu_set_t set_;
         CPU_ZERO(&set_);
         if (sched_getaffinity(0, sizeof(set_), &set_) == 0) usable = (unsigned)std::max(1, CPU_COUNT(&set_));
 #endif
-        n_threads = usable >= 4 ? (int)std::min(8u, usable) : 1;
+        n_threads = (int)std::min(8u, usable);
         if (const char* e_ = std::getenv("CRT_SAH_OPT_THREADS")) n_threads = std::max(1, std::atoi(e_));
-        if (n_threads == 1) return optimize_sah_serial(nodes, passes); // (one thread: the serial form does without the read sets and the overlay)
     }
     struct N { Box box; int parent, child[2]; int32_t leaf_ref; double area; };
     std::vector<N> t((size_t)2 * A + 1);
@@ -381,7 +382,6 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
     };
     double margin = 0.5;
     if (const char* e_ = std::getenv("CRT_SAH_OPT_MARGIN")) margin = std::atof(e_);
-    std::vector<int> stamp((size_t)n_all, -1); // block in which a node's box or links last changed
     struct Cand { double ind; int x; };
     struct alignas(64) Work { // per thread (cache lines of its own: the vectors' headers are written at every push)
         std::vector<Cand> heap;
@@ -390,17 +390,12 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
         std::vector<Box> sbox;      // their boxes with x taken out
         std::vector<double> sarea;
     };
-    struct alignas(64) Spec { int best_x; std::vector<int> read; }; // (a cache line each: neighbours are written by different threads)
-    // the search for node x on the tree as it is, x's removal emulated; `read` collects every node whose box or links it looked at
-    auto search = [&](int x, Work& w, Spec& out) {
-        out.read.clear();
+    // the search for node x on the tree as it is, x's removal emulated: the node to put x beside, or -1 when x stays
+    auto search = [&](int x, Work& w) -> int {
         const int P = t[x].parent;
-        out.best_x = -1;
-        out.read.push_back(x);
-        if (P < 0 || P == root) return;
+        if (P < 0 || P == root) return -1;
         const int S = t[P].child[0] == x ? t[P].child[1] : t[P].child[0];
         const int G = t[P].parent;
-        out.read.push_back(P); out.read.push_back(S); out.read.push_back(G);
         // the root path without x: boxes shrink until one comes out as it was
         w.path.clear(); w.sbox.clear(); w.sarea.clear();
         {
@@ -408,7 +403,6 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
             int below = P;
             for (int y = G; y >= 0; below = y, y = t[y].parent) {
                 const int other = t[y].child[0] == below ? t[y].child[1] : t[y].child[0];
-                out.read.push_back(y); out.read.push_back(other);
                 Box b = cur;
                 b.grow(t[other].box);
                 if (y != G && same_box(b, t[y].box)) break; // (from here up nothing changes; G itself is always on the path: its children differ)
@@ -421,6 +415,9 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
         auto area_of = [&](int c) { return w.pidx[c] >= 0 ? w.sarea[(size_t)w.pidx[c]] : t[c].area; };
         const Box bx = t[x].box;
         const double ax = t[x].area;
+        // A move must pay: `orig` is what putting x back beside its old sibling costs, and a new place has to beat it by the margin (default
+        // one half; CRT_SAH_OPT_MARGIN) -- reinsertions that gain next to nothing only stir up overlap, and with the bound known beforehand
+        // the search ends near the root for the nodes that stay (most of them)
         double best = DBL_MAX;
         int best_x = S;
         if (margin > 0.0) {
@@ -428,10 +425,9 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
             u.grow(bx);
             double orig = u.half_area();
             for (int y = G; y >= 0; y = t[y].parent) {
-                out.read.push_back(y);
                 Box v = box_of(y);
                 v.grow(bx);
-                if (same_box(v, box_of(y))) break;
+                if (same_box(v, box_of(y))) break; // (x lies inside y's box, hence inside every ancestor's: nothing more is added)
                 orig += v.half_area() - area_of(y);
             }
             best = orig * (1.0 - margin);
@@ -443,8 +439,7 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
             std::pop_heap(w.heap.begin(), w.heap.end(), cmp);
             const Cand c = w.heap.back();
             w.heap.pop_back();
-            if (c.ind + ax >= best) break;
-            out.read.push_back(c.x);
+            if (c.ind + ax >= best) break; // the cheapest induced cost left cannot beat the best position any more
             Box u = box_of(c.x);
             u.grow(bx);
             const double direct = u.half_area();
@@ -454,18 +449,17 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
                 if (ind + ax < best) {
                     int k0 = t[c.x].child[0], k1 = t[c.x].child[1];
                     if (c.x == G) { if (k0 == P) k0 = S; else k1 = S; } // (P is gone: its sibling hangs under G)
-                    if (k0 > k1) std::swap(k0, k1);
                     for (int k : {k0, k1}) { w.heap.push_back(Cand{ind, k}); std::push_heap(w.heap.begin(), w.heap.end(), cmp); }
                 }
             }
         }
         for (int y : w.path) w.pidx[y] = -1;
-        out.best_x = best_x;
+        return best_x == S ? -1 : best_x;
     };
     std::vector<Work> work((size_t)n_threads);
     for (Work& w : work) w.pidx.assign((size_t)n_all, -1);
     // a pool of n_threads - 1 helpers; the calling thread works too.  The helpers SPIN between blocks (a block is under a millisecond of
-    // work: waking a sleeping thread takes about as long, and the helpers then find the block done) -- for the few tens of milliseconds of a pass
+    // work: waking a sleeping thread takes about as long, and the helpers then find the block done) -- for the few milliseconds of a pass
     struct Pool {
         std::vector<std::thread> th;
         std::atomic<int> gen{0}, running{0};
@@ -501,63 +495,70 @@ inline int optimize_sah(std::vector<Node>& nodes, int passes, int n_threads = 0)
                 if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
         }
     };
-    const int BLOCK = 512;
-    std::vector<Spec> spec((size_t)BLOCK);
-    int block_id = 0;
+    // blocks of 64, 128, ... 2048 nodes (constants: the tree that comes out must not depend on the machine): the large nodes at the head of the
+    // list are where the moves are and where one move changes what the next should do
+    const int HEAD = CRT_SAH_HEAD, BLOCK0 = 8, BLOCK = 2048;
+    std::vector<int> found((size_t)BLOCK);
     for (int pass = 0; pass < passes; pass++) {
-        std::vector<int> order;
+        // largest first; one 64-bit key per node (the area as a float, inverted, above the id) so that the sort compares integers
+        std::vector<uint64_t> keys;
+        keys.reserve((size_t)n_all);
         for (int x = 0; x < n_all; x++)
-            if (x != root && t[x].parent != root) order.push_back(x);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a].area != t[b].area ? t[a].area > t[b].area : a < b; });
-        for (size_t b0 = 0; b0 < order.size(); b0 += BLOCK, block_id++) {
-            const int nb = (int)std::min<size_t>(BLOCK, order.size() - b0);
+            if (x != root && t[x].parent != root) {
+                const float af = (float)t[x].area;
+                uint32_t bits;
+                std::memcpy(&bits, &af, 4);
+                keys.push_back(((uint64_t)(0xffffffffu - bits) << 32) | (uint32_t)x); // (areas are >= 0: their bit patterns order like the values)
+            }
+        std::sort(keys.begin(), keys.end());
+        const int blk_max = std::min(BLOCK, std::max(BLOCK0, (int)(keys.size() / 64)));
+        const size_t serial_head = (size_t)HEAD;
+        int blk = 1;
+        for (size_t b0 = 0; b0 < keys.size(); b0 += (size_t)blk, blk = b0 < serial_head ? 1 : std::min(blk_max, std::max(BLOCK0, blk * 2))) {
+            const int nb = (int)std::min<size_t>((size_t)blk, keys.size() - b0);
             std::atomic<int> next{0};
-            run_all([&](int tid) {
+            if (nb == 1) found[0] = search((int)(uint32_t)keys[b0], work[0]);
+            else run_all([&](int tid) {
                 for (;;) {
-                    const int i0 = next.fetch_add(8);
+                    const int i0 = next.fetch_add(16);
                     if (i0 >= nb) break;
-                    for (int i = i0; i < std::min(nb, i0 + 8); i++) search(order[b0 + (size_t)i], work[(size_t)tid], spec[(size_t)i]);
+                    for (int i = i0; i < std::min(nb, i0 + 16); i++) found[(size_t)i] = search((int)(uint32_t)keys[b0 + (size_t)i], work[(size_t)tid]);
                 }
             });
+            bool moved = false;
             for (int i = 0; i < nb; i++) {
-                const int x = order[b0 + (size_t)i];
-                Spec& sp = spec[(size_t)i];
-                bool stale = false;
-                for (int y : sp.read) if (stamp[(size_t)y] == block_id) { stale = true; break; }
-                if (stale) search(x, work[0], sp);
+                int bxn = found[(size_t)i];
+                if (bxn < 0) continue;
+                const int x = (int)(uint32_t)keys[b0 + (size_t)i];
+                // a node that moves is priced again on the tree as the block's earlier moves left it (a few hundred searches per pass)
+                if (moved) bxn = search(x, work[0]);
+                if (bxn < 0) continue;
                 const int P = t[x].parent;
-                if (P < 0 || P == root || sp.best_x < 0) continue;
                 const int S = t[P].child[0] == x ? t[P].child[1] : t[P].child[0];
-                if (sp.best_x == S) { // stays: the serial pass leaves the pair as (sibling, node)
-                    t[P].child[0] = S; t[P].child[1] = x;
-                    continue;
-                }
-                // moves: out of its place (the sibling goes up), in beside best_x; every node whose box or links change is stamped
+                // out of its place (the sibling goes up), in beside bxn; P travels with x as the parent of the pair
                 const int G = t[P].parent;
                 t[G].child[t[G].child[0] == P ? 0 : 1] = S;
                 t[S].parent = G;
-                stamp[(size_t)G] = stamp[(size_t)S] = stamp[(size_t)P] = stamp[(size_t)x] = block_id;
                 for (int y = G; y >= 0; y = t[y].parent) {
                     Box bb = t[t[y].child[0]].box;
                     bb.grow(t[t[y].child[1]].box);
                     if (same_box(bb, t[y].box)) break;
-                    t[y].box = bb; t[y].area = bb.half_area(); stamp[(size_t)y] = block_id;
+                    t[y].box = bb; t[y].area = bb.half_area();
                 }
-                const int bxn = sp.best_x;
                 const int Q = t[bxn].parent;
                 t[P].child[0] = bxn; t[P].child[1] = x;
                 t[P].parent = Q;
                 t[bxn].parent = P; t[x].parent = P;
-                stamp[(size_t)bxn] = block_id;
-                if (Q >= 0) { t[Q].child[t[Q].child[0] == bxn ? 0 : 1] = P; stamp[(size_t)Q] = block_id; }
+                if (Q >= 0) t[Q].child[t[Q].child[0] == bxn ? 0 : 1] = P;
                 else root = P;
                 bool first = true;
                 for (int y = P; y >= 0; y = t[y].parent, first = false) {
                     Box bb = t[t[y].child[0]].box;
                     bb.grow(t[t[y].child[1]].box);
                     if (!first && same_box(bb, t[y].box)) break;
-                    t[y].box = bb; t[y].area = bb.half_area(); stamp[(size_t)y] = block_id;
+                    t[y].box = bb; t[y].area = bb.half_area();
                 }
+                moved = true;
             }
         }
     }

@@ -97,6 +97,7 @@ int fail_hip(const HipFail& f)
 }
 
 float as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+int32_t as_int(float f) { int32_t v; std::memcpy(&v, &f, 4); return v; }
 
 // Builds the device node array (layout: crt_device.h) holding TWO trees over the same leaves:
 //   [0, A)      the SAH tree of crt_accel.h, used by CRT_TRAVERSAL_FAST for rays with finite inv_dir
@@ -146,7 +147,8 @@ int convert_bvh(const crt_scene_desc& d, std::vector<float4>& nodes, std::vector
     {
         const char* opt_ = std::getenv("CRT_SAH_OPT");
         const int passes = opt_ ? std::atoi(opt_) : 1;
-        if (!acc.empty() && passes > 0) depth_fast = crtaccel::optimize_sah(acc, passes);
+        const char* form_ = std::getenv("CRT_SAH_OPT_FORM"); // (A/B hook: "serial" = the pass of rounds 4 / 5, every search on the tree as the last move left it)
+        if (!acc.empty() && passes > 0) depth_fast = (form_ && form_[0] == 's') ? crtaccel::optimize_sah_serial(acc, passes) : crtaccel::optimize_sah(acc, passes);
     }
     if (ai) {
         ai->n_leaves = (uint32_t)prims.size(); ai->n_nodes2 = (uint32_t)acc.size(); ai->on_device = on_device ? 1u : 0u;
@@ -807,8 +809,13 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             HIP_CHECK(hipSetDevice(device));
             void* warm = nullptr;
             const uint32_t zero = 0;
-            HIP_CHECK(hipMalloc(&warm, 4));
-            HIP_CHECK(hipMemcpy(warm, &zero, 4, hipMemcpyHostToDevice));
+            (void)zero;
+            // (round 6: the first copy from / to pageable memory beyond the runtime's small-copy path sets up its staging -- 7.3 - 8.7 ms once
+            // per process, 0.03 ms from then on, tools/copy_probe.cpp -- and was booked on the tree build's first upload and download)
+            std::vector<char> page(4u << 20, 0); // (the 3 MB download of the built tree paid another 8.6 ms after a 512 KB warm-up: the path beyond 1 MB)
+            HIP_CHECK(hipMalloc(&warm, page.size()));
+            HIP_CHECK(hipMemcpy(warm, page.data(), page.size(), hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(page.data(), warm, page.size(), hipMemcpyDeviceToHost));
             HIP_CHECK(hipFree(warm));
             sc->accel.runtime_init_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -1062,16 +1069,65 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             std::vector<uint8_t> mixed(n4, 0);
             for (size_t i = 0; i < n4; i++)
                 for (int k = 0; k < 4; k++) if (topo[i].used[k] && topo[i].ref[k] >= 0) mixed[i] = 1;
+            // The children of a class are ordered by "occupancy", descending: the summed area of the triangles below a child over its box's half
+            // area (round 6).  The traversal takes the NEAREST hit inner child first whatever the slots; the slots decide
+            // the order of the others (the loser of (0,1) is popped before the loser of the final, visit_front), the order of a visit's queue
+            // entries, and the breadth-first numbers.  Against the order the collapse happens to leave: C2 75.86 -> 75.35 ms, veach-mis spp 256
+            // 71.17 -> 70.43, inner visits per ray 4.496 -> 4.490 / 6.740 -> 6.685 (by box area instead: 75.61 / 70.41).  Visiting the any-hit
+            // rays' children in this static order INSTEAD of nearest first was measured in both directions and loses (docs/experiments.md 6.10).
+            // CRT_CHILD_ORDER=none|area: A/B hooks.
+            std::vector<double> prio4(n4 * 4, 0.0);
+            const char* co_ = std::getenv("CRT_CHILD_ORDER");
+            if (!(co_ && co_[0] == 'n')) {
+                const bool by_area = co_ && co_[0] == 'a';
+                std::vector<double> tri_area_below(n4, -1.0);
+                auto leaf_area = [&](int32_t ref) {
+                    const size_t dense = (size_t)(~ref);
+                    const int it = as_int(leaf_geo[dense * 5 + 4].z), cnt = as_int(leaf_geo[dense * 5 + 4].w);
+                    double a = 0.0;
+                    for (int q = 0; q < cnt; q++) {
+                        const crt_triangle& tr = d->tris[(size_t)it + (size_t)q];
+                        const double e1[3] = {(double)tr.v2[0] - tr.v1[0], (double)tr.v2[1] - tr.v1[1], (double)tr.v2[2] - tr.v1[2]};
+                        const double e2[3] = {(double)tr.v3[0] - tr.v1[0], (double)tr.v3[1] - tr.v1[1], (double)tr.v3[2] - tr.v1[2]};
+                        const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                        a += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+                    }
+                    return a;
+                };
+                std::vector<std::pair<int32_t, int>> st_(1, std::make_pair(0, 0)); // post-order over the 4-wide tree
+                while (!st_.empty()) {
+                    const int32_t i = st_.back().first;
+                    int32_t next_ = -1;
+                    for (int k = 0; k < 4 && next_ < 0; k++)
+                        if (topo[(size_t)i].used[k] && topo[(size_t)i].ref[k] >= 0 && tri_area_below[(size_t)topo[(size_t)i].ref[k]] < 0.0) next_ = topo[(size_t)i].ref[k];
+                    if (next_ >= 0) { st_.push_back(std::make_pair(next_, 0)); continue; }
+                    double sum = 0.0;
+                    for (int c = 0; c < 4; c++) {
+                        const Topo4& t = topo[(size_t)i];
+                        if (!t.used[c]) continue;
+                        const double below = t.ref[c] < 0 ? leaf_area(t.ref[c]) : tri_area_below[(size_t)t.ref[c]];
+                        sum += below;
+                        const double ex = (double)t.hi[c][0] - t.lo[c][0], ey = (double)t.hi[c][1] - t.lo[c][1], ez = (double)t.hi[c][2] - t.lo[c][2];
+                        const double ha = ex * ey + ey * ez + ez * ex;
+                        prio4[(size_t)i * 4 + (size_t)c] = by_area ? ha : (ha > 0.0 ? below / ha : 1e30);
+                    }
+                    tri_area_below[(size_t)i] = sum;
+                    st_.pop_back();
+                }
+            }
             // children order: mixed, fringe, leaves, empty; then breadth-first numbers in the two ranges
             std::vector<std::array<int, 4>> order(n4);
             for (size_t i = 0; i < n4; i++) {
                 int o = 0;
-                for (int pass = 0; pass < 4; pass++)
+                for (int pass = 0; pass < 4; pass++) {
+                    const int o0 = o;
                     for (int k = 0; k < 4; k++) {
                         const Topo4& t = topo[i];
                         const int cls = !t.used[k] ? 3 : (t.ref[k] < 0 ? 2 : (mixed[(size_t)t.ref[k]] ? 0 : 1));
                         if (cls == pass) order[i][o++] = k;
                     }
+                    std::stable_sort(order[i].begin() + o0, order[i].begin() + o, [&](int a, int b) { return prio4[i * 4 + (size_t)a] > prio4[i * 4 + (size_t)b]; });
+                }
             }
             uint32_t n_mixed = 0;
             for (size_t i = 0; i < n4; i++) n_mixed += mixed[i];

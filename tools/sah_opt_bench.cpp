@@ -8,7 +8,9 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 int main(int argc, char** argv)
 {
@@ -44,24 +46,46 @@ int main(int argc, char** argv)
         const auto t1 = clk::now();
         depth = crtaccel::optimize_sah(nodes, 1);
         const auto t2 = clk::now();
-        if (r == 0) { // the same pass on one thread and by the serial form of round 4: same tree whatever the threads; same summed area as the serial form
+        if (r == 0) { // the same pass on one thread and by the serial form of round 4: same tree whatever the threads; a tree over the same leaves whose
+                      // boxes are its children's; summed inner area beside the serial form's
             std::vector<crtaccel::Prim> p2 = prims0;
-            std::vector<crtaccel::Node> n1, ns;
+            std::vector<crtaccel::Node> n1, ns, n0;
             int32_t r2 = 0;
             crtaccel::build_sah(p2, n1, r2);
-            ns = n1;
+            ns = n1; n0 = n1;
             const auto u0 = clk::now();
             crtaccel::optimize_sah(n1, 1, 1);
             const auto u1 = clk::now();
             crtaccel::optimize_sah_serial(ns, 1);
             const auto u2 = clk::now();
             const bool same = n1.size() == nodes.size() && std::memcmp(n1.data(), nodes.data(), n1.size() * sizeof(crtaccel::Node)) == 0;
-            double as = 0, a1 = 0;
-            for (const auto& n : ns) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); as += b.half_area(); }
-            for (const auto& n : n1) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); a1 += b.half_area(); }
-            std::printf("{\"one_thread_equals_many\": %s, \"one_thread_ms\": %.2f, \"serial_round4_ms\": %.2f, \"summed_area_serial\": %.6e, \"summed_area_speculative\": %.6e, \"arrays_equal_serial\": %s}\n",
-                        same ? "true" : "false", std::chrono::duration<double, std::milli>(u1 - u0).count(), std::chrono::duration<double, std::milli>(u2 - u1).count(), as, a1,
-                        (ns.size() == n1.size() && std::memcmp(ns.data(), n1.data(), ns.size() * sizeof(crtaccel::Node)) == 0) ? "true" : "false");
+            auto area_of = [](const std::vector<crtaccel::Node>& v) { double a = 0; for (const auto& n : v) { crtaccel::Box b = n.box[0]; b.grow(n.box[1]); a += b.half_area(); } return a; };
+            // validity of the tree the product uses: every inner node reached once from the root, every leaf ref of the built tree present once,
+            // the box stored for an inner child equal to the union of that child's two boxes
+            bool valid = nodes.size() == n0.size();
+            std::vector<int32_t> refs_in, refs_out;
+            for (const auto& n : n0) for (int s = 0; s < 2; s++) if (n.child[s] < 0) refs_in.push_back(n.child[s]);
+            std::vector<char> seen(nodes.size(), 0);
+            std::vector<int> todo(1, 0);
+            size_t reached = 0;
+            while (valid && !todo.empty()) {
+                const int q = todo.back(); todo.pop_back();
+                if (q < 0 || (size_t)q >= nodes.size() || seen[q]) { valid = false; break; }
+                seen[q] = 1; reached++;
+                for (int s = 0; s < 2; s++) {
+                    const int32_t c = nodes[q].child[s];
+                    if (c < 0) { refs_out.push_back(c); continue; }
+                    if ((size_t)c >= nodes.size()) { valid = false; break; }
+                    crtaccel::Box b = nodes[c].box[0]; b.grow(nodes[c].box[1]);
+                    if (std::memcmp(&b, &nodes[q].box[s], sizeof(b)) != 0) valid = false;
+                    todo.push_back(c);
+                }
+            }
+            std::sort(refs_in.begin(), refs_in.end()); std::sort(refs_out.begin(), refs_out.end());
+            valid = valid && reached == nodes.size() && refs_in == refs_out;
+            std::printf("{\"one_thread_equals_many\": %s, \"valid_tree\": %s, \"one_thread_ms\": %.2f, \"serial_round4_ms\": %.2f, \"summed_area_built\": %.6e, \"summed_area_serial\": %.6e, \"summed_area_batched\": %.6e}\n",
+                        same ? "true" : "false", valid ? "true" : "false", std::chrono::duration<double, std::milli>(u1 - u0).count(), std::chrono::duration<double, std::milli>(u2 - u1).count(),
+                        area_of(n0), area_of(ns), area_of(n1));
         }
         best_build = std::min(best_build, std::chrono::duration<double, std::milli>(t1 - t0).count());
         best_opt = std::min(best_opt, std::chrono::duration<double, std::milli>(t2 - t1).count());
