@@ -176,6 +176,10 @@ __device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
     return tl - T > CRT_EPSILON;
 }
 
+// The same with the limit known only as "is +inf" (TRI_CC below): tl - FLT_MAX > EPSILON holds for tl = +inf alone (a finite tl gives <= 0, NaN fails)
+__device__ __forceinline__ bool shadow_blocked_bit(const bool tl_inf, const int tri) { return tri >= 0 || tl_inf; }
+#define ST_TL_INF (1u << 12) /* state word of the la plane, bits 12 .. 15 are free: the in-flight next-event ray's limit is +inf */
+
 // LA: consumes the result of a next-event sample that is not the last one of its vertex, of a closest-hit ray
 // that found a surface, or of a probe ray; enters the vertex if it is new; sets up the next next-event sample.
 // Returns PH3_NONE when a ray was emitted into nr, else the phase the path has to visit instead.
@@ -188,19 +192,28 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // The phase is a chain of dependent loads (path planes -> triangle / material / light tables -> light triangle), and a wave
     // that waits issues nothing: everything whose address is known is fetched up front, needed by this lane's stage or not.
     //   round 1: the path planes and the triangle record of the hit (the new vertex, if this ray found one)
+    // TRI_CC (round 6, every mode but REFERENCE): the vertex's triangle rides in cc.w -- cc is written with every next-event sample and read
+    // by every visit anyway -- instead of a store of its own into the id plane at every vertex; the limit of the sample's ray, which was
+    // there, is needed as "is +inf" only (shadow_blocked) and is a bit of the state word.  REFERENCE compares the limit with the nearest
+    // hit's distance and keeps the round-5 planes.  With the vx plane's store this takes two of ten store instructions per vertex out
+    // of the logic phases: C2 75.8 -> 73.6 (vx) -> see docs/experiments.md 6.12.
+    constexpr bool TRI_CC = CRT_X_NOVN && MODE != 1;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id<RING>(P, g);
+    const uint4 idv = load_path_id<RING, !TRI_CC>(P, g);
+    const float4 cc = gld(&pl.cc[g]); // pending next-event contribution; .w = bits(triangle of the vertex the samples belong to) (REFERENCE: distance to the light sample)
+    const uint32_t st = __float_as_uint(la.w);
+    const uint32_t stage = (st >> 8) & 15u;
+    // (a path's first visit -- its camera ray found vertex 0 -- has no vertex in the planes yet: cc.w is what the slot's last path left, or
+    // never written; the speculative row is then row 0 and is not used)
+    const uint32_t vtri_old = TRI_CC ? ((st & 0xfffu) == ((uint32_t)ST_HIT << 8) ? 0u : __float_as_uint(cc.w)) : idv.w;
 #if CRT_X_NOVN
-    const float4 vn = gld(&sc.tri_nm[idv.w]); // (normal, material) of the vertex in the planes: from its triangle (the id plane's second word)
+    const float4 vn = gld(&sc.tri_nm[vtri_old]); // (normal, material) of the vertex in the planes: from its triangle
 #else
     const float4 vn = gld(&pl.vn[g]);
 #endif
-    const float4 cc = gld(&pl.cc[g]); // pending next-event contribution, .w = distance to the light sample (ST_SHADOW)
     const float res_t = qa.w;
     const int res_tri = __float_as_int(qb.w);
     const float4 gq_hit = gld(&sc.tri_nm[res_tri >= 0 ? res_tri : 0]);
-    const uint32_t st = __float_as_uint(la.w);
-    const uint32_t stage = (st >> 8) & 15u;
     //   round 2: material rows of the vertex the samples belong to after this visit (the new one for ST_HIT), row 1 of the
     //   vertex the ray left (specular flag, ST_HIT), and the light of the sample that is set up below
     //   (the vn plane of a slot's very first vertex has never been written: the speculative index is clamped into the table)
@@ -221,11 +234,12 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     s.pixel_index = idv.x; s.k = idv.y; s.item = idv.z;
     s.ro = f3(qa.x, qa.y, qa.z); s.tl = 0.0f;
     s.rd = f3(qb.x, qb.y, qb.z);
-    s.pos = s.ro; s.vtri = 0; s.c = f3(0.0f, 0.0f, 0.0f); s.kind = RAY_NONE;
+    s.pos = s.ro; s.vtri = vtri_old; s.c = f3(0.0f, 0.0f, 0.0f); s.kind = RAY_NONE;
     bool do_enter = false;
     if (stage == ST_SHADOW) {
         // visibility of next-event sample q (Render.cuh:19-27, :272-284); shadow rays start at the vertex: s.pos == s.ro
-        if (!shadow_blocked<MODE>(cc.w, res_t, res_tri)) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
+        const bool blocked = TRI_CC ? shadow_blocked_bit((st & ST_TL_INF) != 0u, res_tri) : shadow_blocked<MODE>(cc.w, res_t, res_tri);
+        if (!blocked) s.Ld = add3(s.Ld, f3(cc.x, cc.y, cc.z));
         s.q++;
     } else if (stage == ST_HIT) {
         // the camera / bounce ray found vertex `depth` (Render.cuh:207-213)
@@ -295,20 +309,23 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         s.nrm = f3(gq.x, gq.y, gq.z);
         s.mat = TNM_MAT(__float_as_uint(gq.w));
         gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
-        gst(&pl.vx[g], make_float4(s.pos.x, s.pos.y, s.pos.z, __uint_as_float(s.vtri)));
+        // (round 6: the vertex position is not written to the vx plane any more -- LB takes it from the slot's ray record, which is a
+        // next-event ray of this vertex or, for a vertex without one, is given the position below.  The plane lives on for the probe rays.)
 #if CRT_X_NOVN
-        store_path_tri(P, g, s.vtri);
+        if (!TRI_CC) store_path_tri(P, g, s.vtri);
 #else
         gst(&pl.vn[g], make_float4(s.nrm.x, s.nrm.y, s.nrm.z, __uint_as_float(s.mat)));
 #endif
-        if (TNM_EMITTER(tnm_cur)) { // emitter: the path ends here (Render.cuh:210)
-            gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16))));
+        if (TNM_EMITTER(tnm_cur)) { // emitter: the path ends here (Render.cuh:210); TRI_CC: LC finds the emitter's triangle in la.x
+            gst(&pl.la[g], make_float4(TRI_CC ? __uint_as_float(s.vtri) : 0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_FIN << 8) | (1u << 16))));
             return PH3_LC;
         }
         s.Ld = f3(0.0f, 0.0f, 0.0f);
         s.q = 0;
         if (n_nee == 0) {
             gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8))));
+            if (TRI_CC) gst(&pl.cc[g].w, __uint_as_float(s.vtri)); // (a vertex without a sample: its triangle for LB and for the next vertex's visit)
+            nr.o = s.pos; // (no ray: the caller puts the position into the slot's ray record for LB)
             return PH3_LB;
         }
     }
@@ -337,11 +354,13 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         s.q++;
         if (s.q == n_nee) { // that was the last sample of the vertex: on to the roulette
             gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_NEED << 8))));
+            if (TRI_CC) gst(&pl.cc[g].w, __uint_as_float(s.vtri)); // (every sample of the vertex may have been answered here: none has written cc)
+            nr.o = s.pos;
             return PH3_LB;
         }
     }
-    gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16))));
-    gst(&pl.cc[g], make_float4(s.c.x, s.c.y, s.c.z, s.tl));
+    gst(&pl.la[g], make_float4(s.Ld.x, s.Ld.y, s.Ld.z, __uint_as_float(s.depth | ((uint32_t)ST_SHADOW << 8) | (s.q << 16) | ((TRI_CC && s.tl == pinf()) ? ST_TL_INF : 0u))));
+    gst(&pl.cc[g], make_float4(s.c.x, s.c.y, s.c.z, TRI_CC ? __uint_as_float(s.vtri) : s.tl));
     nr.o = s.ro; nr.d = s.rd; nr.tl = s.tl; nr.kind = RAY_SHADOW;
     nr.flags = RF_SHADOW | (s.q + 1 == n_nee ? RF_LAST : 0u) | (skip ? RF_SKIP : 0u);
     return PH3_NONE;
@@ -352,15 +371,17 @@ template <int MODE, bool RING = false>
 __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, const float4 qa, const float4 qb, NewRay& nr)
 {
     const Pool& pl = P.pool;
+    constexpr bool TRI_CC = CRT_X_NOVN && MODE != 1; // (see logic_A)
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id<RING>(P, g);
+    const uint4 idv = load_path_id<RING, !TRI_CC>(P, g);
     const float4 cc = gld(&pl.cc[g]); // (with the other planes, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     uint32_t depth = st & 255u;
     F3 Ld = f3(la.x, la.y, la.z);
     if (stage == ST_SHADOW) { // the last next-event sample (Render.cuh:272-284)
-        if (!shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w))) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
+        const bool blocked = TRI_CC ? shadow_blocked_bit((st & ST_TL_INF) != 0u, __float_as_int(qb.w)) : shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w));
+        if (!blocked) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
     gst_rec(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, 0.0f));
     bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
@@ -374,11 +395,13 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
         gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8))));
         return PH3_LC;
     }
+    // the vertex: the origin of the slot's last ray -- a next-event ray starts at its vertex (setup_shadow_lg) -- or what LA's caller put there
 #if CRT_X_NOVN
-    const float4 vn = gld(&P.sc.tri_nm[idv.w]), vx = gld(&pl.vx[g]);
+    const float4 vn = gld(&P.sc.tri_nm[TRI_CC ? __float_as_uint(cc.w) : idv.w]);
 #else
-    const float4 vn = gld(&pl.vn[g]), vx = gld(&pl.vx[g]);
+    const float4 vn = gld(&pl.vn[g]);
 #endif
+    const float4 vx = qa;
     const F3 ndir = unit3(sample_hemisphere(f3(vn.x, vn.y, vn.z), rng_uniform(rb.y), rng_uniform(rb.z)));
     depth++;
     gst(&pl.la[g], make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8))));
@@ -391,12 +414,13 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
 // with the camera ray of a new path, or -- commit ring only -- LC_WAIT: the slot holds a work item it may not start yet and comes
 // back to this phase.  fin_key: see ring_publish.
 enum { LC_DEAD = 0, LC_RAY = 1, LC_WAIT = 2 };
-template <bool RING>
+template <int MODE, bool RING>
 __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb, const uint32_t g, PathCounters& cnt, NewRay& nr, uint32_t& fin_key)
 {
+    constexpr bool TRI_CC = CRT_X_NOVN && MODE != 1; // (see logic_A: an emitter's triangle arrives in la.x)
     const Pool& pl = P.pool;
     const float4 la = gld(&pl.la[g]);
-    const uint4 idv = load_path_id<RING>(P, g); // (with la, not after the stage is known: one round trip less, see logic_A)
+    const uint4 idv = load_path_id<RING, !TRI_CC>(P, g); // (with la, not after the stage is known: one round trip less, see logic_A)
     const uint32_t st = __float_as_uint(la.w);
     const uint32_t stage = (st >> 8) & 15u;
     const uint32_t depth = st & 255u;
@@ -423,7 +447,7 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
         else if ((st >> 16) & 1u) {
             emissive = true;
 #if CRT_X_NOVN
-            const float4 m2 = mat_row(tb, TNM_MAT(__float_as_uint(gld(&P.sc.tri_nm[idv.w]).w)), 2);
+            const float4 m2 = mat_row(tb, TNM_MAT(__float_as_uint(gld(&P.sc.tri_nm[TRI_CC ? __float_as_uint(la.x) : idv.w]).w)), 2);
 #else
             const float4 m2 = mat_row(tb, __float_as_uint(gld(&pl.vn[g]).w), 2);
 #endif
@@ -1583,6 +1607,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 float4 ra_, rb_;
                 ray_result(S, id, ra_, rb_);
                 nph = logic_A<MODE, RING>(Pl, tl, g, ra_, rb_, nr, cnt, ALL);
+                if (nph == PH3_LB) { S.A[id].x = nr.o.x; S.A[id].y = nr.o.y; S.A[id].z = nr.o.z; } // (a vertex that goes to the roulette without a ray of its own)
                 if (nph == PH3_NONE) nph = start_ray<MODE, false, LDS3, IMPL>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
             }
             n_exact += (int)__popcll(__ballot(new_exact));
@@ -1640,7 +1665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_WAVES, C
                 NewRay nr;
                 float4 ra_ = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rb_ = ra_;
                 if (QUERY) ray_result(S, id, ra_, rb_);
-                const int got = QUERY ? (query_C(Pl, g, ra_, rb_, nr) ? LC_RAY : LC_DEAD) : logic_C<RING>(Pl, tl, g, cnt, nr, fin_key);
+                const int got = QUERY ? (query_C(Pl, g, ra_, rb_, nr) ? LC_RAY : LC_DEAD) : logic_C<MODE, RING>(Pl, tl, g, cnt, nr, fin_key);
                 if (got == LC_RAY) nph = start_ray<MODE, QUERY, LDS3, IMPL>(Pl.sc, S, id, nr, cnt, M3.force_exact != 0, new_exact);
                 wait = got == LC_WAIT;
             }

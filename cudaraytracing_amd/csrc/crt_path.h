@@ -420,12 +420,16 @@ __device__ __forceinline__ void setup_shadow(const LParams& P, const Tables<LDS_
 #ifndef CRT_X_NOVN
 #define CRT_X_NOVN 1
 #endif
+// Round 6: in every mode but CRT_TRAVERSAL_REFERENCE the triangle rides in the w word of the cc plane instead -- written
+// with every next-event sample anyway -- and the id plane is read as the work item alone (TRI = false); see logic_A.
 #if CRT_X_NOVN
-template <bool RING = false>
+template <bool RING = false, bool TRI = true>
 __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
 {
     typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
-    const u2v_ w = *(const CRT_GAS u2v_*)((const uint2*)P.pool.id + g);
+    u2v_ w;
+    if (TRI) w = *(const CRT_GAS u2v_*)((const uint2*)P.pool.id + g);
+    else { w.x = *(const CRT_GAS uint32_t*)((const uint32_t*)((const uint2*)P.pool.id + g)); w.y = 0u; }
     uint32_t pixel_index, k, pi, pj;
     bool valid;
     decode_item<RING>(P, w.x, pixel_index, k, valid, pi, pj);
@@ -442,7 +446,7 @@ __device__ __forceinline__ void store_path_tri(const LParams& P, const uint32_t 
     *(CRT_GAS uint32_t*)((uint32_t*)((uint2*)P.pool.id + g) + 1) = tri;
 }
 #else
-template <bool RING = false>
+template <bool RING = false, bool TRI = true>
 __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g)
 {
     const uint32_t item = gld((const uint32_t*)P.pool.id + g);
