@@ -176,6 +176,53 @@ __device__ __forceinline__ bool shadow_blocked(float tl, float T, int tri)
     return tl - T > CRT_EPSILON;
 }
 
+// Backward recursion over k_mega3's vertex records, deepest first (Render.cuh:238-326; crt_path.h: finish_path is the wavefront pipeline's).
+// Round 6 layout: vertex j of a path that went ON from it has  rec_a[j] = (L_dir.xyz, bits(triangle-row word: material | flags)), written
+// by LB when the roulette lets the path continue, and  rec_b[j].w = cos to vertex j + 1, written when that vertex is found (rec_b[j].xyz,
+// the direction that arrived at j, is written for SPECULAR vertices only: nothing else reads it).  The deepest vertex has no record: its
+// L_dir arrives in the la plane (`have_ld`) when the path stopped there, is rec_a's when the ray that left it found nothing, and is not
+// needed when it is an emitter.  Against one 16-byte record store more per vertex and one per path that stops (round 5).
+__device__ __forceinline__ F3 finish_path_m3(const LParams& P, const Tables<false>& tb, const uint32_t slot, const int deepest, const bool emissive, const F3 ke,
+                                            const bool have_ld, const F3 ld)
+{
+    const Pool& pl = P.pool;
+    F3 L = f3(0.0f, 0.0f, 0.0f);
+    if (deepest < 0) return L;
+    const float inv_pdf_sphere = (float)(2.0f * 3.14159265358979323846); // Global.h:96-99
+    if (emissive) {
+        L = deepest == 0 ? add3(f3(0.0f, 0.0f, 0.0f), ke) : f3(0.0f, 0.0f, 0.0f); // :249-255, :323
+    } else if (have_ld) {
+        L = add3(f3(0.0f, 0.0f, 0.0f), ld); // final hit: direct light only (:316-319)
+    } else {
+        const float4 a = gld_rec(&pl.rec_a[(size_t)deepest * pl.n + slot]);
+        L = add3(f3(0.0f, 0.0f, 0.0f), f3(a.x, a.y, a.z));
+    }
+    // (the loads of CRT_FINISH_PF vertices are fetched together, as in finish_path)
+    for (int v = deepest - 1; v >= 0; v -= CRT_FINISH_PF) {
+        float4 a[CRT_FINISH_PF], fm[CRT_FINISH_PF];
+        float cs[CRT_FINISH_PF];
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) {
+            const int vj = v - j > 0 ? v - j : 0;
+            a[j] = gld_rec(&pl.rec_a[(size_t)vj * pl.n + slot]);
+            cs[j] = __uint_as_float(gld((const uint32_t*)&pl.rec_b[(size_t)vj * pl.n + slot].w));
+        }
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) fm[j] = mat_row(tb, TNM_MAT(__float_as_uint(a[j].w)), 0);
+#pragma unroll
+        for (int j = 0; j < CRT_FINISH_PF; j++) {
+            if (v - j >= 0) {
+                F3 ind = mul3(L, f3(fm[j].x, fm[j].y, fm[j].z)); // L (.) f_r * cos * inv_pdf / P_RR  (:293)
+                ind = scale3(ind, cs[j]);
+                ind = scale3(ind, inv_pdf_sphere);
+                ind = div3(ind, P.p_rr);
+                L = add3(ind, f3(a[j].x, a[j].y, a[j].z)); // :323
+            }
+        }
+    }
+    return L;
+}
+
 // The same with the limit known only as "is +inf" (TRI_CC below): tl - FLT_MAX > EPSILON holds for tl = +inf alone (a finite tl gives <= 0, NaN fails)
 __device__ __forceinline__ bool shadow_blocked_bit(const bool tl_inf, const int tri) { return tri >= 0 || tl_inf; }
 #define ST_TL_INF (1u << 12) /* state word of the la plane, bits 12 .. 15 are free: the in-flight next-event ray's limit is +inf */
@@ -251,7 +298,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
             const F3 pn = s.nrm;
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray
             cos_prev = cos_prev > 0.0f ? cos_prev : 0.0f;
-            gst_rec(&pl.rec_a[pr].w, cos_prev);
+            gst_rec(&pl.rec_b[pr].w, cos_prev); // (finish_path_m3: the cosine lives in rec_b.w, rec_a.w is the vertex's material)
             if (TNM_SPECULAR(__float_as_uint(vn.w))) { // SPECULAR: emitter probe, Render.cuh:294-303
                 const float ns = mat_row(tb, s.mat, 0).w;
                 const float4 pb = gld_rec(&pl.rec_b[pr]); // direction that arrived at the previous vertex
@@ -308,7 +355,8 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         }
         s.nrm = f3(gq.x, gq.y, gq.z);
         s.mat = TNM_MAT(__float_as_uint(gq.w));
-        gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, __uint_as_float(s.mat)));
+        // (the direction that arrived: read by the probe of a SPECULAR vertex when the next vertex is found, by nothing else)
+        if (TNM_SPECULAR(tnm_cur)) gst_rec(&pl.rec_b[(size_t)s.depth * pl.n + g], make_float4(s.rd.x, s.rd.y, s.rd.z, 0.0f));
         // (round 6: the vertex position is not written to the vx plane any more -- LB takes it from the slot's ray record, which is a
         // next-event ray of this vertex or, for a vertex without one, is given the position below.  The plane lives on for the probe rays.)
 #if CRT_X_NOVN
@@ -383,7 +431,6 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
         const bool blocked = TRI_CC ? shadow_blocked_bit((st & ST_TL_INF) != 0u, __float_as_int(qb.w)) : shadow_blocked<MODE>(cc.w, qa.w, __float_as_int(qb.w));
         if (!blocked) Ld = add3(Ld, f3(cc.x, cc.y, cc.z));
     }
-    gst_rec(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, 0.0f));
     bool stop = depth == CRT_BOUNCE_STACK_SIZE - 1; // bounce stack full
     U4 rb;
     rb.x = rb.y = rb.z = rb.w = 0;
@@ -391,8 +438,8 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
         rb = rng_draw(P.seed, idv.x, idv.y, depth, RNG_BOUNCE, 0);
         stop = rng_uniform(rb.x) > P.p_rr;
     }
-    if (stop) {
-        gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(depth | ((uint32_t)ST_FIN << 8))));
+    if (stop) { // the deepest vertex: its L_dir goes to LC in the la plane, it has no record (finish_path_m3)
+        gst(&pl.la[g], make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_FIN << 8))));
         return PH3_LC;
     }
     // the vertex: the origin of the slot's last ray -- a next-event ray starts at its vertex (setup_shadow_lg) -- or what LA's caller put there
@@ -402,7 +449,10 @@ __device__ __forceinline__ uint32_t logic_B(const LParams& P, const uint32_t g, 
     const float4 vn = gld(&pl.vn[g]);
 #endif
     const float4 vx = qa;
+    gst_rec(&pl.rec_a[(size_t)depth * pl.n + g], make_float4(Ld.x, Ld.y, Ld.z, vn.w)); // the vertex's record: L_dir and its material (with the row's flag bits)
     const F3 ndir = unit3(sample_hemisphere(f3(vn.x, vn.y, vn.z), rng_uniform(rb.y), rng_uniform(rb.z)));
+    // (leaving this store out -- the plane then still holds a state only LB consumes, which LA and LC can read as "the ray for vertex depth + 1
+    // is in flight" -- was measured in round 6: C2 +0.4 %, veach-mis +0.3 %: LA's load of the line then misses the L2 the store had left it in)
     depth++;
     gst(&pl.la[g], make_float4(Ld.x, Ld.y, Ld.z, __uint_as_float(depth | ((uint32_t)ST_HIT << 8))));
     nr.o = f3(vx.x, vx.y, vx.z); nr.d = unit3(ndir); /* Ray.cuh:13 */ nr.tl = 0.0f; nr.kind = RAY_CLOSEST; nr.flags = 0;
@@ -453,7 +503,7 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
 #endif
             ke = f3(m2.x, m2.y, m2.z);
         }
-        const F3 L = finish_path(P, tb, g, deepest, emissive, ke);
+        const F3 L = finish_path_m3(P, tb, g, deepest, emissive, ke, stage == ST_FIN && !emissive, f3(la.x, la.y, la.z));
         if (ring) {
             const uint32_t sh = fast_div(idv.z, P.items_per_shard_div.m, P.items_per_shard_div.sh), c = idv.z - sh * P.items_per_shard;
             const uint32_t s = fast_div(c, P.spsh_div.m, P.spsh_div.sh), rs = s & P.ring_mask;
