@@ -10,6 +10,9 @@
 
 namespace crtk {
 
+#ifndef CRT_X_SLIGHT
+#define CRT_X_SLIGHT 1 /* 0: the light table through vector loads only (A/B) */
+#endif
 struct NewRay {
     F3 o, d;
     float tl;
@@ -266,6 +269,8 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     //   (the vn plane of a slot's very first vertex has never been written: the speculative index is clamped into the table)
     // (round 6: "is an emitter" / "is SPECULAR" ride in the two top bits of the triangle row's material word -- rows 1 of two materials were
     // fetched for those two bits alone, and what bounds this kernel is the NUMBER of vector-memory instructions)
+    // (the material word of the samples' vertex in the id plane's free second word, so that its BSDF row is fetched WITH the triangle row instead
+    // of after it, was measured in round 6: C2 +0.8 % -- one more store per vertex, and the round it saves is not the phase's last)
     const uint32_t mat_old = min(TNM_MAT(__float_as_uint(vn.w)), P.n_mats - 1u);
     const uint32_t mat_cur = stage == ST_HIT ? TNM_MAT(__float_as_uint(gq_hit.w)) : mat_old;
     uint32_t tnm_cur = stage == ST_HIT ? __float_as_uint(gq_hit.w) : __float_as_uint(vn.w);
@@ -273,7 +278,15 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     const uint32_t n_nee = (uint32_t)(sc.n_lights * P.lsn);
     const uint32_t q_next = stage == ST_SHADOW ? (st >> 16) + 1 : 0u;
     uint4 lg_next = make_uint4(0u, 1u, 0u, 0u);
-    if (n_nee > 0) lg_next = gld(&tb.lights[fast_div(q_next < n_nee ? q_next : 0u, P.lsn_div.m, P.lsn_div.sh)]);
+    // A scene with ONE light has its table entry fetched through the scalar cache: one vector load per visit fewer (round 6: C2 72.11 -> 71.75 ms).
+    // (The eight rows of a light of <= 2 triangles -- the quad of a Cornell box -- fetched the same way and picked per lane: C2 level, and
+    // veach-mis, which does not take that path, +1.2 % from the second copy of the set-up code; not kept.)
+    if (n_nee > 0) {
+        if (CRT_X_SLIGHT && sc.n_lights == 1) {
+            const crt_u4v_ l0_ = *(const __attribute__((address_space(4))) crt_u4v_*)tb.lights;
+            lg_next = make_uint4(l0_.x, l0_.y, l0_.z, l0_.w);
+        } else lg_next = gld(&tb.lights[fast_div(q_next < n_nee ? q_next : 0u, P.lsn_div.m, P.lsn_div.sh)]);
+    }
     Lane s;
     s.depth = st & 255u; s.q = st >> 16; s.stage = stage;
     s.Ld = f3(la.x, la.y, la.z);

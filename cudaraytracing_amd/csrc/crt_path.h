@@ -478,7 +478,9 @@ __device__ __forceinline__ F3 finish_path(const LParams& P, const Tables<LDS_TAB
     // The recursion is a serial chain, but its loads are not: the records (and material rows) of CRT_FINISH_PF vertices are
     // fetched together, so a chunk costs two memory round trips instead of two per vertex (lanes with fewer vertices re-read
     // vertex 0 and skip the arithmetic).
+#ifndef CRT_FINISH_PF
 #define CRT_FINISH_PF 4
+#endif
     for (int v = deepest - 1; v >= 0; v -= CRT_FINISH_PF) {
         float4 a[CRT_FINISH_PF], fm[CRT_FINISH_PF];
         uint32_t mat[CRT_FINISH_PF];
