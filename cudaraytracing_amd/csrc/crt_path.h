@@ -140,7 +140,8 @@ __device__ __forceinline__ void gst(uint4* p, const uint4 v) { crt_u4v_ t; t.x =
 __device__ __forceinline__ void gst(float* p, const float v) { *(CRT_GAS float*)p = v; }
 // The vertex records (rec_a / rec_b): written when a vertex is entered, read once when the path ends.  (Streaming them past the L2 -- nt
 // loads and stores -- was measured in round 5: fabric traffic 348.6 -> 330.8 GB, L2 miss rate 0.475 -> 0.418, and the frame +14 %: the reads
-// at a path's end then always go to the memory side, and LC waits for them.  Plain accesses.)
+// at a path's end then always go to the memory side, and LC waits for them.  Round 6, the STORES alone streamed, the loads plain: C2 +7.4 %,
+// veach-mis +6.0 % -- the records' lines are still in L2 when the path ends.  Plain accesses.)
 __device__ __forceinline__ float4 gld_rec(const float4* p) { return gld(p); }
 __device__ __forceinline__ void gst_rec(float4* p, const float4 v) { gst(p, v); }
 __device__ __forceinline__ void gst_rec(float* p, const float v) { gst(p, v); }
