@@ -564,13 +564,13 @@ __device__ __forceinline__ int logic_C(const LParams& P, const Tables<false>& tb
         if (!valid) continue; // padding slot of a ragged tile: take another item
         if (ring && !ring_gate_open(P, item, home_, home_word_)) { // its sample's slot of the ring is not free yet: hold the item
             if (!waiting) {
-                store_path_id(P, g, item);
+                store_path_id<!TRI_CC>(P, g, item);
                 gst(&pl.la[g], make_float4(0.0f, 0.0f, 0.0f, __uint_as_float((uint32_t)ST_WAIT << 8)));
             }
             return LC_WAIT;
         }
         cnt.paths++;
-        if (!waiting) store_path_id(P, g, item);
+        if (!waiting) store_path_id<!TRI_CC>(P, g, item);
         const U4 rj = rng_draw(P.seed, pixel_index, k, 0, RNG_JITTER, 0);
         const float x = (2 * ((int)pi + rng_uniform(rj.x)) / P.width - 1) * P.scale * P.ar;
         const float y = (1 - 2 * ((int)pj + rng_uniform(rj.y)) / P.height) * P.scale;

@@ -430,15 +430,17 @@ __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g
     typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
     u2v_ w;
     if (TRI) w = *(const CRT_GAS u2v_*)((const uint2*)P.pool.id + g);
-    else { w.x = *(const CRT_GAS uint32_t*)((const uint32_t*)((const uint2*)P.pool.id + g)); w.y = 0u; }
+    else { w.x = *(const CRT_GAS uint32_t*)((const uint32_t*)P.pool.id + g); w.y = 0u; } // (the work items alone, densely: the first half of the plane)
     uint32_t pixel_index, k, pi, pj;
     bool valid;
     decode_item<RING>(P, w.x, pixel_index, k, valid, pi, pj);
     return make_uint4(pixel_index, k, w.x, w.y);
 }
+template <bool TRI = true>
 __device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t item)
 {
     typedef uint32_t u2v_ __attribute__((ext_vector_type(2)));
+    if (!TRI) { *(CRT_GAS uint32_t*)((uint32_t*)P.pool.id + g) = item; return; }
     u2v_ w; w.x = item; w.y = 0u; // (triangle 0: a valid row of tri_nm for the speculative load of a path's first visit)
     *(CRT_GAS u2v_*)((uint2*)P.pool.id + g) = w;
 }
@@ -456,6 +458,7 @@ __device__ __forceinline__ uint4 load_path_id(const LParams& P, const uint32_t g
     decode_item<RING>(P, item, pixel_index, k, valid, pi, pj);
     return make_uint4(pixel_index, k, item, 0u);
 }
+template <bool TRI = true>
 __device__ __forceinline__ void store_path_id(const LParams& P, const uint32_t g, const uint32_t item)
 {
     *(CRT_GAS uint32_t*)((uint32_t*)P.pool.id + g) = item;
