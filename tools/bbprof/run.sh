@@ -4,7 +4,9 @@
 set -o pipefail
 tag=${1:-bb}; spp=${2:-8}
 co=tools/bbprof/out/k_mega3_bb.co
-[ -f $co ] || tools/bbprof/build_co.sh > /dev/null || exit 1
+# (always rebuilt: a code object left from an earlier state of the sources travels to the box with the snapshot and would be profiled in
+# place of the kernel in the tree -- it renders the same frame, so nothing else notices; BBPROF_KEEP=1 reuses it)
+if [ "${BBPROF_KEEP:-0}" != 1 ] || [ ! -f $co ]; then rm -rf tools/bbprof/out; tools/bbprof/build_co.sh > /dev/null || exit 1; fi
 mkdir -p gpurun_out/$tag; cp tools/bbprof/out/k_mega3_bb.json gpurun_out/$tag/
 export CRT_BBPROF_CO=$co
 CRT_BBPROF_OUT=gpurun_out/$tag/smoke.txt timeout -k 10 300 python3 __graft_entry__.py --smoke > gpurun_out/$tag/smoke.log 2>&1 || { echo "instrumented smoke failed"; tail -5 gpurun_out/$tag/smoke.log; exit 2; }
