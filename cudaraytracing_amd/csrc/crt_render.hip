@@ -13,6 +13,7 @@
 #include <string>
 #include <type_traits>
 #include <array>
+#include <atomic>
 #include <vector>
 
 using namespace crtdev;
@@ -807,16 +808,20 @@ int crt_scene_create(const crt_scene_desc* d, int device, crt_scene** out)
             // so that it is not booked on whatever happens to come first (it was the SAH build's first upload: "147 ms" of tree building)
             const auto t0 = std::chrono::steady_clock::now();
             HIP_CHECK(hipSetDevice(device));
-            void* warm = nullptr;
-            const uint32_t zero = 0;
-            (void)zero;
             // (round 6: the first copy from / to pageable memory beyond the runtime's small-copy path sets up its staging -- 7.3 - 8.7 ms once
-            // per process, 0.03 ms from then on, tools/copy_probe.cpp -- and was booked on the tree build's first upload and download)
-            std::vector<char> page(4u << 20, 0); // (the 3 MB download of the built tree paid another 8.6 ms after a 512 KB warm-up: the path beyond 1 MB)
-            HIP_CHECK(hipMalloc(&warm, page.size()));
-            HIP_CHECK(hipMemcpy(warm, page.data(), page.size(), hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(page.data(), warm, page.size(), hipMemcpyDeviceToHost));
-            HIP_CHECK(hipFree(warm));
+            // per process, 0.03 ms from then on, tools/copy_probe.cpp -- and was booked on the tree build's first upload and download; the 3 MB
+            // download of the built tree paid another 8.6 ms after a 512 KB warm-up: the path beyond 1 MB.  Once per device and process.)
+            static std::atomic<uint64_t> warmed{0};
+            const uint64_t bit = 1ull << (device & 63);
+            if (!(warmed.fetch_or(bit) & bit)) {
+                std::vector<char> page(4u << 20, 0);
+                DevBuf<char> warm;
+                warm.ensure(page.size());
+                HIP_CHECK(hipMemcpy(warm.p, page.data(), page.size(), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMemcpy(page.data(), warm.p, page.size(), hipMemcpyDeviceToHost));
+            } else {
+                HIP_CHECK(hipFree(nullptr)); // (the context, if this thread has none yet)
+            }
             sc->accel.runtime_init_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
         std::vector<float4> nodes, geo(d->n_tris * 3ull), mats(d->n_materials * 3ull), ltri(d->n_light_tris * 4ull);
