@@ -245,8 +245,8 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     // TRI_CC (round 6, every mode but REFERENCE): the vertex's triangle rides in cc.w -- cc is written with every next-event sample and read
     // by every visit anyway -- instead of a store of its own into the id plane at every vertex; the limit of the sample's ray, which was
     // there, is needed as "is +inf" only (shadow_blocked) and is a bit of the state word.  REFERENCE compares the limit with the nearest
-    // hit's distance and keeps the round-5 planes.  With the vx plane's store this takes two of ten store instructions per vertex out
-    // of the logic phases: C2 75.8 -> 73.6 (vx) -> see docs/experiments.md 6.12.
+    // hit's distance and keeps the round-5 planes.  (docs/experiments.md 6.12: the store of the vertex position that went with it was the
+    // gain, C2 75.8 -> 73.6 ms; this one is level in time and takes 6.7 % off the bytes written.)
     constexpr bool TRI_CC = CRT_X_NOVN && MODE != 1;
     const float4 la = gld(&pl.la[g]);
     const uint4 idv = load_path_id<RING, !TRI_CC>(P, g);
@@ -266,7 +266,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
     const float4 gq_hit = gld(&sc.tri_nm[res_tri >= 0 ? res_tri : 0]);
     //   round 2: material rows of the vertex the samples belong to after this visit (the new one for ST_HIT), row 1 of the
     //   vertex the ray left (specular flag, ST_HIT), and the light of the sample that is set up below
-    //   (the vn plane of a slot's very first vertex has never been written: the speculative index is clamped into the table)
+    //   (the material word of a slot's very first vertex comes from row 0, see vtri_old: the index is clamped into the table all the same)
     // (round 6: "is an emitter" / "is SPECULAR" ride in the two top bits of the triangle row's material word -- rows 1 of two materials were
     // fetched for those two bits alone, and what bounds this kernel is the NUMBER of vector-memory instructions)
     // (the material word of the samples' vertex in the id plane's free second word, so that its BSDF row is fetched WITH the triangle row instead
@@ -306,7 +306,7 @@ __device__ __forceinline__ uint32_t logic_A(const LParams& P, const Tables<false
         const F3 pos = add3(s.ro, scalel3(res_t, s.rd)); // DeviceTriangle.cuh:50
         do_enter = true;
         if (s.depth > 0) {
-            // the previous vertex (normal / material still in the vn plane) is not the deepest one: cosine of its indirect term (Render.cuh:291)
+            // the previous vertex (vn: its triangle's row) is not the deepest one: cosine of its indirect term (Render.cuh:291)
             const size_t pr = (size_t)(s.depth - 1) * pl.n + g;
             const F3 pn = s.nrm;
             float cos_prev = dot3(unit3(sub3(pos, s.ro)), pn); // prev.pos == origin of this ray

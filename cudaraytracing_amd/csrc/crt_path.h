@@ -44,14 +44,14 @@ enum { RAY_NONE = 0, RAY_CLOSEST = 1, RAY_SHADOW = 2 };
 struct Pool {
     float4* ro;   // ray origin.xyz, t_limit (shadow rays: Render.cuh:272)
     float4* rd;   // ray direction.xyz (normalised as Ray does), bits(ray kind)
-    float4* vx;   // current vertex position.xyz, bits(triangle)
+    float4* vx;   // current vertex position.xyz, bits(triangle) (k_mega3, round 6: only the vertex that waits for a SPECULAR probe's result)
     float4* la;   // next-event accumulator L_dir.xyz of the current vertex, bits(depth | stage << 8 | sample << 16)
-    float4* cc;   // contribution of the in-flight shadow ray .xyz, bits(work item)
+    float4* cc;   // contribution of the in-flight shadow ray .xyz, distance to the light sample (k_mega3 but for REFERENCE: bits(the vertex's triangle))
     float4* vn;   // normal.xyz and bits(material) of the current vertex (of the PREVIOUS vertex while a bounce ray is in flight)
-    uint4* id;    // pixel index, sample index, work item, unused -- written once per path
+    uint4* id;    // pixel index, sample index, work item, unused -- written once per path (k_mega3: the work item alone, 4 B; REFERENCE: + triangle, 8 B)
     float2* res;  // result of the slot's last ray: t, bits(triangle or -1)
-    float4* rec_a; // [depth][n]: L_dir.xyz of that vertex, cos to the next vertex
-    float4* rec_b; // [depth][n]: incoming direction.xyz, bits(material)
+    float4* rec_a; // [depth][n]: L_dir.xyz of that vertex, cos to the next vertex                (k_mega3: L_dir.xyz, bits(material word) -- finish_path_m3)
+    float4* rec_b; // [depth][n]: incoming direction.xyz, bits(material)                           (k_mega3: direction of SPECULAR vertices only, cos to the next vertex)
     uint32_t n;
 };
 
