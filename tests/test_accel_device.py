@@ -138,3 +138,49 @@ def test_collapse_by_dynamic_programming_against_the_greedy_one(name, monkeypatc
             assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot))
     finally:
         dp.free(); gr.free()
+
+
+TREE_HOOKS = {  # environment of crt_scene_create's tree set-up (csrc/crt_render.hip, csrc/crt_accel.h)
+    "default": {},
+    "children of a node as the collapse leaves them": {"CRT_CHILD_ORDER": "none"},
+    "children of a node by box area": {"CRT_CHILD_ORDER": "area"},
+    "re-insertion pass: serial form": {"CRT_SAH_OPT_FORM": "serial"},
+    "re-insertion pass: one thread": {"CRT_SAH_OPT_THREADS": "1"},
+    "re-insertion pass: two passes, margin 0.3": {"CRT_SAH_OPT": "2", "CRT_SAH_OPT_MARGIN": "0.3"},
+    "no re-insertion pass": {"CRT_SAH_OPT": "0"},
+}
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "veach-mis"])
+def test_tree_set_up_hooks_change_the_tree_and_not_the_frame(name, monkeypatch):
+    """Round 6: the children of a four-wide node are ordered by occupancy, and the re-insertion pass runs in blocks on several threads
+    (tests/test_sah_opt.py checks the pass on the CPU).  Every hook of the set-up gives another tree over the SAME leaves: the frame, the
+    ray count and the closest hits of random rays stay the oracle's in both exact-by-construction modes and in FAST; the batched pass
+    gives the same tree on one thread as on many (here: the same number of four-wide nodes and the same depths)."""
+    t = util.task(name)
+    eye, iv, fov = util.camera(name)
+    osc = util.oracle_scene(name)
+    orgb, omean, _, st = osc.render(eye, iv, fov, 96, 72, 2, t.P_RR, t.light_sample_n)
+    o, d = util.random_rays(name, 2048, seed=11)
+    otri, ot, _ = osc.intersect(o, d)
+    seen = {}
+    for hook, env in TREE_HOOKS.items():
+        for k in ("CRT_CHILD_ORDER", "CRT_SAH_OPT_FORM", "CRT_SAH_OPT_THREADS", "CRT_SAH_OPT", "CRT_SAH_OPT_MARGIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = crt.Render(util.host_scene(name), 2, t.P_RR, t.light_sample_n)
+        try:
+            for mode in (crt.TRAVERSAL_EXACT, crt.TRAVERSAL_FAST):
+                r.traversal = mode
+                rgb = r.run_view(eye, iv, fov, stats=True, width=96, height=72)
+                assert np.array_equal(rgb, orgb) and np.array_equal(util.bits(r.mean_buffer), util.bits(omean)), (hook, mode)
+                assert r.stats["rays"] == st["rays"], (hook, mode)
+                if mode == crt.TRAVERSAL_EXACT:
+                    a = r.accel_info()
+                    seen[hook] = (a["n_nodes4"], a["depth2"], a["depth4"])  # (visit counts of any-hit rays depend on the waves' timing: not compared)
+            tri, tt = r.intersect(o, d, traversal=crt.TRAVERSAL_EXACT)
+            assert np.array_equal(tri, otri) and np.array_equal(util.bits(tt), util.bits(ot)), hook
+        finally:
+            r.free()
+    assert seen["default"] == seen["re-insertion pass: one thread"], seen
